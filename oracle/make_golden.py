@@ -1,0 +1,269 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF.  Build container only.
+
+Imports the reference's own hot-path modules from /root/reference (read-only, never
+copied) after registering build-owned stand-ins for the three third-party symbols that
+are absent from this image:
+
+  timm.models.vision_transformer.Mlp      -> fc1 / act / fc2 with the same attribute names
+  xformers.ops.memory_efficient_attention -> torch SDPA on the transposes
+  torchdiffeq.odeint                      -> fixed-grid solver restated from torchdiffeq's
+                                            published algorithm ('rk4' = 3/8 rule); this
+                                            part is therefore NOT pinned by third-party code.
+
+Then runs the reference classes (nn.vit.ViT, CaloChallengeCFM, CFM._batch_loss,
+sample_batch, torch.optim.AdamW + clip_grad_norm_ as in BaseExperiment._step) on seeded
+synthetic CaloChallenge-shaped inputs and stores inputs + outputs as small fixtures.
+Weights are not stored: both sides fill them with oracle.vit_cfm_oracle.golden_fill.
+
+Usage:  python oracle/make_golden.py     (writes tests/golden/*.npz)
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+
+from oracle import vit_cfm_oracle as O  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stand-ins
+def _install_standins():
+    class Mlp(nn.Module):  # timm Mlp: fc1 -> act -> drop1 -> norm(Identity) -> fc2 -> drop2
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.drop1 = nn.Dropout(drop)
+            self.norm = nn.Identity()
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop2 = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
+
+    timm = types.ModuleType("timm")
+    timm_models = types.ModuleType("timm.models")
+    timm_vt = types.ModuleType("timm.models.vision_transformer")
+    timm_vt.Mlp = Mlp
+    timm.models = timm_models
+    timm_models.vision_transformer = timm_vt
+    sys.modules.update({"timm": timm, "timm.models": timm_models, "timm.models.vision_transformer": timm_vt})
+
+    def memory_efficient_attention(q, k, v, p=0.0):  # (B,T,H,dh) in / out
+        o = torch.nn.functional.scaled_dot_product_attention(
+            q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), dropout_p=p
+        )
+        return o.transpose(1, 2)
+
+    xf = types.ModuleType("xformers")
+    xf_ops = types.ModuleType("xformers.ops")
+    xf_ops.memory_efficient_attention = memory_efficient_attention
+    xf.ops = xf_ops
+    sys.modules.update({"xformers": xf, "xformers.ops": xf_ops})
+
+    def odeint(func, y0, t, method="rk4", options=None, **kw):
+        step = (options or {}).get("step_size", None)
+        assert step is not None, "stand-in supports fixed-grid solvers with options.step_size only"
+        grid = O.fixed_grid(float(t[0]), float(t[-1]), step, y0.dtype)
+        y = y0
+        for k in range(len(grid) - 1):
+            y = O.ode_step(func, method, grid[k], grid[k + 1], y)
+        return torch.stack([y0, y])
+
+    tde = types.ModuleType("torchdiffeq")
+    tde.odeint = odeint
+    sys.modules["torchdiffeq"] = tde
+
+
+def build_reference(cfg: O.ViTConfig, use_torch_sdpa=True):
+    from experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM
+    from nn.vit import ViT
+
+    l, a, r = cfg.num_patches
+    param = {
+        "dim": 3,
+        "condition_dim": cfg.condition_dim,
+        "hidden_dim": cfg.hidden_dim,
+        "out_channels": 1,
+        "depth": cfg.depth,
+        "num_heads": cfg.num_heads,
+        "mlp_ratio": cfg.mlp_ratio,
+        "attn_drop": 0.0,
+        "proj_drop": 0.0,
+        "pos_embedding_coords": "cylindrical",
+        "temperature": 10000,
+        "learn_pos_embed": True,
+        "causal_attn": False,
+        "checkpoint_grads": False,
+        "num_patches": [[l, a, r]],
+        "patch_dim": cfg.P,
+        "use_torch_sdpa": use_torch_sdpa,
+    }
+    net = ViT(param)
+    model = CaloChallengeCFM(
+        net,
+        list(cfg.patch_shape),
+        in_channels=1,
+        time_distribution="uniform",
+        trajectory="linear",
+        odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}},
+        shape=list(cfg.shape),
+    )
+    model.device = torch.device("cpu")
+    model.dtype = torch.float32
+    return model
+
+
+def load_fill(model, cfg):
+    fill = O.golden_fill(cfg)
+    sd = model.state_dict()
+    for k, v in fill.items():
+        assert sd["net." + k].shape == v.shape, (k, sd["net." + k].shape, v.shape)
+        sd["net." + k] = v.clone()
+    model.load_state_dict(sd)
+    return fill
+
+
+def grad_probe(g: torch.Tensor, n=48):
+    """A fixed, size-independent sample of a gradient tensor: first 8 + strided 40."""
+    f = g.detach().flatten().double()
+    idx = np.unique(np.concatenate([np.arange(min(8, f.numel())), np.linspace(0, f.numel() - 1, 40).astype(np.int64)]))
+    return idx, f[idx].numpy()
+
+
+def make_case(name, cfg, B, seed, sample_specs, train_steps):
+    torch.manual_seed(1234)
+    model = build_reference(cfg)
+    # param inventory check against the oracle's list (names, shapes, order)
+    ref_names = [k[4:] for k, _ in model.named_parameters()]
+    assert ref_names == list(O.param_shapes(cfg).keys()), "state-dict order/name mismatch"
+    nparams = sum(p.numel() for p in model.parameters())
+    load_fill(model, cfg)
+    model.train()
+
+    x, c, g = O.synthetic_batch(cfg, B, seed)
+    out = {"x": x.numpy(), "c": c.numpy(), "nparams": np.int64(nparams)}
+
+    # --- _batch_loss through the reference's own code path (models/base_model.py:203-218).
+    # It draws t then x0 from the global CPU generator; re-seeding reproduces both.
+    torch.manual_seed(seed + 100)
+    loss = model._batch_loss([x, c])
+    torch.manual_seed(seed + 100)
+    t = torch.rand([B, 1, 1, 1, 1])
+    x0 = torch.randn_like(x)
+    with torch.no_grad():
+        x_t = (1 - t) * x0 + t * x
+        v = model.forward(x_t, t.view(-1, 1), c)
+        assert torch.allclose(((v - (x - x0)) ** 2).mean(), loss, rtol=0, atol=0), "t/x0 replay mismatch"
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    out.update({"t": t.numpy(), "x0": x0.numpy(), "velocity": v.numpy(), "loss": np.float64(loss.item())})
+    names, norms = [], []
+    for k, p_ in model.named_parameters():
+        k = k[4:]
+        idx, vals = grad_probe(p_.grad)
+        out["gidx/" + k] = idx
+        out["gval/" + k] = vals
+        names.append(k)
+        norms.append(float(p_.grad.double().norm()))
+    out["grad_norms"] = np.array(norms)
+    out["grad_total_norm"] = np.float64(np.sqrt((np.array(norms) ** 2).sum()))
+
+    # --- the xformers-branch stand-in must agree with the SDPA branch (nn/vit.py:432-448)
+    # --- token-level intermediates for per-kernel parity (ViT.forward on patches)
+    with torch.no_grad():
+        xp = model.to_patches(x_t)
+        out["patches"] = xp.numpy()
+        out["pos_embed"] = model.net.learnable_pos_embedding().numpy()
+        out["tokens_out"] = model.net(xp, t.view(-1, 1), c).numpy()
+        out["t_emb"] = model.net.t_embedder(t.view(-1, 1)).numpy()
+        out["c_emb"] = model.net.c_embedder(c).numpy()
+
+    # --- sampling (calochallenge_cfm/model.py:68-94) with x_T replayed from the global RNG
+    for tag, method, step in sample_specs:
+        model.odeint_kwargs = {"method": method, "options": {"step_size": step}}
+        model.eval()
+        torch.manual_seed(seed + 200)
+        s = model.sample_batch(c)
+        torch.manual_seed(seed + 200)
+        x_T = torch.randn((B, 1, *cfg.shape))
+        out["x_T"] = x_T.numpy()
+        out[f"sample/{tag}"] = s.numpy()
+        out[f"sample_meta/{tag}"] = np.array([step])
+    model.train()
+
+    # --- update-step trajectory (experiments/base_experiment.py:555-597; configs/training/default.yaml)
+    if train_steps:
+        load_fill(model, cfg)
+        iters = 50
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=iters, eta_min=0)
+        gt = torch.Generator().manual_seed(seed + 300)
+        losses, gnorms, ts, x0s = [], [], [], []
+        for _ in range(train_steps):
+            t_k, x0_k = O.synthetic_noise(cfg, B, gt)
+            x_t = (1 - t_k) * x0_k + t_k * x
+            vel = model.forward(x_t, t_k.view(-1, 1), c)
+            l_k = ((vel - (x - x0_k)) ** 2).mean()
+            opt.zero_grad(set_to_none=True)
+            l_k.backward()
+            torch.nn.utils.clip_grad_norm_(model.net.parameters(), float("inf"))
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1000.0, error_if_nonfinite=True)
+            opt.step()
+            sched.step()
+            losses.append(l_k.item())
+            gnorms.append(gn.item())
+            ts.append(t_k.numpy())
+            x0s.append(x0_k.numpy())
+        out["train/losses"] = np.array(losses)
+        out["train/gnorms"] = np.array(gnorms)
+        out["train/t"] = np.stack(ts)
+        out["train/x0"] = np.stack(x0s)
+        out["train/iters"] = np.int64(iters)
+        sd = model.state_dict()
+        for k in ("net.pos_embed_freqs", "net.blocks.0.attn.qkv.bias", "net.final_layer.linear.bias"):
+            out["train/final/" + k[4:]] = sd[k].numpy()
+
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={loss.item():.6f} |g|={out['grad_total_norm']:.6f} nparams={nparams} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+def check_branches(cfg):
+    """SDPA branch vs (stand-in) xformers branch of nn/vit.py:431-449 must agree."""
+    a = build_reference(cfg, True)
+    b = build_reference(cfg, False)
+    load_fill(a, cfg)
+    load_fill(b, cfg)
+    x, c, g = O.synthetic_batch(cfg, 2, 5)
+    t = torch.rand(2, 1, generator=g)
+    with torch.no_grad():
+        d = (a.forward(x, t, c) - b.forward(x, t, c)).abs().max().item()
+    print("sdpa vs xformers-stand-in max abs diff:", d)
+    assert d < 1e-5
+
+
+def main():
+    _install_standins()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(8)
+    check_branches(O.ds2(2))
+    make_case("ds2_d2_b2", O.ds2(2), 2, 11, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)], 5)
+    make_case("ds2_d6_b2", O.ds2(6), 2, 12, [("rk4_coarse", "rk4", 0.25)], 3)
+    make_case("ds3_d6_b1", O.ds3(6), 1, 13, [("rk4_coarse", "rk4", 0.5)], 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""Pins the CPU oracle (oracle/vit_cfm_oracle.py) against vectors produced by the reference
+itself (oracle/make_golden.py -> tests/golden/*.npz).  CPU only."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_cfm_oracle as O
+
+CASES = {"ds2_d2_b2": O.ds2(2), "ds2_d6_b2": O.ds2(6), "ds3_d6_b1": O.ds3(6)}
+RTOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order only
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_param_inventory(name, golden):
+    g = golden(name)
+    cfg = CASES[name]
+    n = sum(int(np.prod(s)) for s in O.param_shapes(cfg).values())
+    assert n == int(g["nparams"])
+    assert n == {"ds2_d2_b2": 9424928, "ds2_d6_b2": 26042528, "ds3_d6_b1": 26082890}[name]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_loss_grads(name, golden):
+    g = golden(name)
+    cfg = CASES[name]
+    p = O.golden_fill(cfg)
+    x, c, t, x0 = (torch.from_numpy(g[k]) for k in ("x", "c", "t", "x0"))
+    # the synthetic generator is part of the contract too
+    seed = {"ds2_d2_b2": 11, "ds2_d6_b2": 12, "ds3_d6_b1": 13}[name]
+    xs, cs, _ = O.synthetic_batch(cfg, x.shape[0], seed)
+    assert torch.equal(xs, x) and torch.equal(cs, c)
+
+    xt = (1 - t) * x0 + t * x
+    assert rel(O.to_patches(xt, cfg).numpy(), g["patches"]) == 0.0
+    assert rel(O.pos_embedding(p["pos_embed_freqs"], cfg).numpy(), g["pos_embed"]) < RTOL
+    te = O.timestep_embedding(t.view(-1, 1), cfg.freq_dim)
+    te = O.linear(O.silu(O.linear(te, p, "t_embedder.mlp.0")), p, "t_embedder.mlp.2")
+    assert rel(te.numpy(), g["t_emb"]) < RTOL
+    assert rel(O.vit_forward(p, O.to_patches(xt, cfg), t.view(-1, 1), c, cfg).numpy(), g["tokens_out"]) < RTOL
+
+    loss, v, grads = O.loss_and_grads(p, x, c, t, x0, cfg)
+    assert rel(v.numpy(), g["velocity"]) < RTOL
+    assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < RTOL
+    names = list(O.param_shapes(cfg))
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    assert np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max() < 5e-5
+    for k in names:
+        got = grads[k].flatten().double().numpy()[g["gidx/" + k]]
+        scale = max(float(np.abs(g["gval/" + k]).max()), 1e-3 * float(g["grad_norms"][names.index(k)]), 1e-12)
+        assert np.abs(got - g["gval/" + k]).max() / scale < 2e-4, k
+
+
+@pytest.mark.parametrize("name,tag,method", [("ds2_d2_b2", "rk4", "rk4"), ("ds2_d2_b2", "heun", "heun2"),
+                                             ("ds2_d6_b2", "rk4_coarse", "rk4"), ("ds3_d6_b1", "rk4_coarse", "rk4")])
+def test_sampler(name, tag, method, golden):
+    g = golden(name)
+    cfg = CASES[name]
+    p = O.golden_fill(cfg)
+    s = O.sample(p, torch.from_numpy(g["c"]), torch.from_numpy(g["x_T"]), cfg, method, float(g[f"sample_meta/{tag}"][0]))
+    assert rel(s.numpy(), g[f"sample/{tag}"]) < 1e-4
+
+
+def test_fixed_grid():
+    g = O.fixed_grid(0.0, 1.0, 0.05)
+    assert len(g) == 21 and float(g[-1]) == 1.0 and float(g[0]) == 0.0
+    assert len(O.fixed_grid(0.0, 1.0, 0.25)) == 5
+
+
+@pytest.mark.parametrize("name", ["ds2_d2_b2", "ds2_d6_b2"])
+def test_update_step_trajectory(name, golden):
+    """AdamW + clip + cosine LR as in BaseExperiment._step (base_experiment.py:555-597)."""
+    g = golden(name)
+    cfg = CASES[name]
+    p = O.golden_fill(cfg)
+    st = O.AdamWState(iterations=int(g["train/iters"]))
+    x, c = torch.from_numpy(g["x"]), torch.from_numpy(g["c"])
+    for k in range(len(g["train/losses"])):
+        loss, gn = O.train_step(p, st, x, c, torch.from_numpy(g["train/t"][k]), torch.from_numpy(g["train/x0"][k]), cfg)
+        assert abs(loss - g["train/losses"][k]) / g["train/losses"][k] < 1e-4, (k, loss)
+        assert abs(gn - g["train/gnorms"][k]) / g["train/gnorms"][k] < 1e-3, (k, gn)
+    for k in ("pos_embed_freqs", "blocks.0.attn.qkv.bias", "final_layer.linear.bias"):
+        assert rel(p[k].numpy(), g["train/final/" + k]) < 1e-4, k
+
+
+def test_hash_fill_is_platform_independent():
+    u = O.hash_uniform("x_embedder.weight", 5)
+    # integers only -> these exact values on every platform
+    assert np.all(np.abs(u) < 1.0)
+    assert (u * (1 << 23)).tolist() == [float(int(v)) for v in (u * (1 << 23))]
+    v = O.hash_uniform("x_embedder.weight", 5)
+    assert np.array_equal(u, v)
+    assert not np.array_equal(u, O.hash_uniform("x_embedder.bias", 5))
