@@ -1,0 +1,111 @@
+/* vit4hep_hip.h - C ABI of libvit4hep_hip.so: the MI355X (gfx950) implementation of the ViT-CFM hot path of
+ * luigifvr/vit4hep.  Plain pointers and sizes only; every pointer named d_* is a DEVICE pointer (HBM), `stream`
+ * is a hipStream_t passed as void*.  All entry points return 0 on success, non-zero on error
+ * (v4h_last_error() gives the message); none of them synchronises, allocates device memory or touches the host
+ * copy of any tensor, so a caller may capture them into a hipGraph.
+ *
+ * The reference has no native boundary of its own (pure Python): each entry point below replaces
+ * the PyTorch/timm/xformers/torchdiffeq calls of the cited reference lines (paths relative to the reference
+ * repository root).  The Python host mirror of the reference classes that binds this ABI is
+ * vit4hep_amd/nn/vit.py (class ViT) and vit4hep_amd/models (CFM, CaloChallengeCFM); see INTEGRATION.md.
+ */
+#ifndef VIT4HEP_HIP_H
+#define VIT4HEP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V4H_ABI_VERSION 1
+
+/* arithmetic mode of the contractions */
+#define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
+#define V4H_MODE_BF16 1 /* bf16 MFMA (v_mfma_f32_16x16x32_bf16), f32 accumulate, bf16 activations: throughput mode */
+
+/* Network + geometry description.  Mirrors ViT.__init__'s `param` mapping (nn/vit.py:52-73) and
+ * CaloChallengeCFM.__init__ (experiments/calochallenge/calochallenge_cfm/model.py:9-38). */
+typedef struct v4h_config {
+  int32_t shape[3];       /* voxel grid (L, A, R)                 cfm_ds2_electrons.yaml:3  */
+  int32_t patch_shape[3]; /* (p1, p2, p3)                         cfm_ds2_electrons.yaml:4  */
+  int32_t in_channels;    /* must be 1                            cfm_ds2_electrons.yaml:2  */
+  int32_t condition_dim;  /* 46                                   nn/vit.py:54              */
+  int32_t hidden_dim;     /* 480                                  nn/vit.py:55              */
+  int32_t depth;          /* 6                                    nn/vit.py:57              */
+  int32_t num_heads;      /* 6                                    nn/vit.py:58              */
+  int32_t mlp_hidden;     /* int(hidden_dim * mlp_ratio) = 1920   nn/vit.py:312             */
+  int32_t freq_dim;       /* 256 TimestepEmbedder                 nn/vit.py:359             */
+  int32_t mode;           /* V4H_MODE_*                                                     */
+} v4h_config;
+
+typedef struct v4h_plan v4h_plan; /* host-side object: derived sizes and workspace offsets, no device state */
+
+int32_t v4h_abi_version(void);
+const char* v4h_last_error(void);
+
+/* ---- plan ------------------------------------------------------------------------------------------------ */
+int32_t v4h_plan_create(const v4h_config* cfg, v4h_plan** out);
+void v4h_plan_destroy(v4h_plan* plan);
+/* number of learnable tensors (= 11 + 10*depth + 4) and, for index i, its element count / rows / cols in the
+ * reference's state_dict() order (nn/vit.py:76-132: pos_embed_freqs, x_embedder.{weight,bias},
+ * c_embedder.{0,2}.{weight,bias}, t_embedder.mlp.{0,2}.{weight,bias}, blocks.i.{attn.qkv, attn.proj, mlp.fc1,
+ * mlp.fc2, adaLN_modulation.1}.{weight,bias}, final_layer.{linear, adaLN_modulation.1}.{weight,bias}) */
+int32_t v4h_plan_num_params(const v4h_plan* plan);
+int32_t v4h_plan_param_shape(const v4h_plan* plan, int32_t index, int32_t* rows, int32_t* cols);
+/* bytes of device workspace needed for batch size B; training != 0 keeps every activation the backward needs */
+size_t v4h_plan_workspace_bytes(const v4h_plan* plan, int32_t B, int32_t training);
+
+/* ---- network: CaloChallengeCFM.forward = to_patches -> ViT.forward -> from_patches
+ *      (calochallenge_cfm/model.py:62-66, nn/vit.py:185-206) and its backward (autograd of the same) -------- */
+/* d_params: host array of v4h_plan_num_params() device pointers to f32 tensors in the order above.
+ * d_x (B,1,L,A,R) f32, d_t (B) f32, d_c (B,condition_dim) f32 -> d_out (B,1,L,A,R) f32. */
+int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
+                        float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream);
+/* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
+ * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
+ * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce
+ * with the remaining backward: stage 0 = final layer, stage 1+j = block depth-1-j, stage depth+1 = embedders
+ * (x/t/c embedders + pos_embed_freqs).  Stages must be run in increasing order, each exactly once. */
+int32_t v4h_vit_backward(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout, void* d_workspace,
+                         size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream);
+int32_t v4h_vit_num_backward_stages(const v4h_plan* plan);
+
+/* ---- CFM step pieces ------------------------------------------------------------------------------------- */
+/* linear_trajectory + target (models/trajectories.py:5-8, models/base_model.py:214): x_t = (1-t) x0 + t x1, target = x1 - x0 */
+int32_t v4h_cfm_prepare(const float* d_x1, const float* d_x0, const float* d_t, float* d_xt, float* d_target, int32_t B, int64_t per_sample, void* stream);
+/* loss = mean((v - target)^2) (models/base_model.py:217-218); d_dv (optional) = d loss / d v */
+int32_t v4h_mse_loss(const float* d_v, const float* d_target, float* d_loss, float* d_dv, int64_t n, void* stream);
+/* sum of squares accumulated into d_out[0] (clip_grad_norm_, experiments/base_experiment.py:562-585) */
+int32_t v4h_sq_norm_accum(const float* d_g, int64_t n, float* d_out, void* stream);
+/* clip_grad_norm_(max_norm) + torch.optim.AdamW step on one flat tensor (experiments/base_experiment.py:573-592,
+ * configs/training/default.yaml:5-10).  d_gnorm_sq may be NULL (no clipping).  step >= 1 is the AdamW step count. */
+int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
+int32_t v4h_axpby(float* d_out, const float* d_a, const float* d_b, float alpha, float beta, int64_t n, void* stream);
+int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const float* d_k3, const float* d_k4, float h, int64_t n, void* stream);
+
+/* ---- single operators (unit parity tests; the network entry points above are built from these) ----------- */
+/* out[i][j] = sum_k P[i][k] Q[j][k] (+ bias[j]); P/Q row-major with the given leading dims; *_kstrided != 0 means the
+ * operand is stored [k][idx].  out is `mode`-typed unless out_f32 != 0.  nn.Linear forward/dgrad/wgrad. */
+int32_t v4h_op_gemm(int32_t mode, const void* d_P, int32_t ldp, int32_t p_kstrided, const void* d_Q, int32_t ldq, int32_t q_kstrided, const float* d_bias,
+                    void* d_out, int32_t ldo, int32_t out_f32, int32_t I, int32_t J, int32_t K, int32_t splitk, float* d_colsum, void* stream);
+/* softmax(q k^T / sqrt(dh)) v on token-major qkv (B*T, 3*H*dh) -> o (B*T, H*dh), lse (B,H,T)   nn/vit.py:425-451 */
+int32_t v4h_op_attention_fwd(int32_t mode, const void* d_qkv, void* d_o, float* d_lse, int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
+int32_t v4h_op_attention_bwd(int32_t mode, const void* d_qkv, const void* d_o, const void* d_do, const float* d_lse, float* d_delta, void* d_dqkv,
+                             int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
+/* LayerNorm(eps 1e-6, no affine) + modulate   nn/vit.py:309,457-458 ; shift/scale (B, ld_mod-strided) f32 */
+int32_t v4h_op_ln_modulate_fwd(int32_t mode, const float* d_x, const float* d_shift, const float* d_scale, int32_t ld_mod, void* d_u, float* d_mean,
+                               float* d_rstd, int32_t B, int32_t T, int32_t D, void* stream);
+/* to_patches / from_patches   calochallenge_cfm/model.py:40-60 ; tokens are f32 (B*T, P) */
+int32_t v4h_op_patchify(const v4h_plan* plan, const float* d_vox, float* d_tokens, int32_t B, void* stream);
+int32_t v4h_op_unpatchify(const v4h_plan* plan, const float* d_tokens, float* d_vox, int32_t B, void* stream);
+/* learnable_pos_embedding   nn/vit.py:156-162 -> (T, D) f32 */
+int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT4HEP_HIP_H */

@@ -1,0 +1,160 @@
+"""ctypes binding of libvit4hep_hip.so (C ABI: include/vit4hep_hip.h).
+
+The product path has no fallback: if the library is missing or an entry point fails, a
+RuntimeError is raised.  PyTorch is used only for device memory and streams.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvit4hep_hip.so")
+
+MODE_F32 = 0
+MODE_BF16 = 1
+MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
+
+
+class V4HConfig(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int32 * 3),
+        ("patch_shape", C.c_int32 * 3),
+        ("in_channels", C.c_int32),
+        ("condition_dim", C.c_int32),
+        ("hidden_dim", C.c_int32),
+        ("depth", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("mlp_hidden", C.c_int32),
+        ("freq_dim", C.c_int32),
+        ("mode", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); exactly the declarations of include/vit4hep_hip.h
+SIGNATURES = {
+    "v4h_abi_version": (_i32, []),
+    "v4h_last_error": (C.c_char_p, []),
+    "v4h_plan_create": (_i32, [C.POINTER(V4HConfig), _pp]),
+    "v4h_plan_destroy": (None, [_vp]),
+    "v4h_plan_num_params": (_i32, [_vp]),
+    "v4h_plan_param_shape": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "v4h_plan_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "v4h_vit_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp]),
+    "v4h_vit_num_backward_stages": (_i32, [_vp]),
+    "v4h_cfm_prepare": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+    "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
+    "v4h_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "v4h_axpby": (_i32, [_vp, _vp, _vp, _f32, _f32, _i64, _vp]),
+    "v4h_rk4_combine": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp]),
+    "v4h_op_gemm": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "v4h_op_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "v4h_op_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "v4h_op_ln_modulate_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "v4h_op_patchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "v4h_op_unpatchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "v4h_op_pos_embed": (_i32, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises loudly when it is absent: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m vit4hep_amd.build` (hipcc, gfx950). "
+            "vit4hep_amd has no CPU or PyTorch fallback for the ViT-CFM path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.v4h_abi_version() != 1:
+        raise RuntimeError(f"libvit4hep_hip.so ABI {lib.v4h_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().v4h_last_error().decode(errors="replace")
+        raise RuntimeError(f"libvit4hep_hip {what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"{name} must be a tensor on the MI355X (cuda) device: vit4hep_amd runs the ViT-CFM path only through its HIP library"
+        )
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def pointer_table(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class Plan:
+    """Host-side plan (sizes + workspace layout) for one (geometry, network, mode)."""
+
+    def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1):
+        lib = load()
+        cfg = V4HConfig()
+        cfg.shape[:] = [int(v) for v in shape]
+        cfg.patch_shape[:] = [int(v) for v in patch_shape]
+        cfg.in_channels = int(in_channels)
+        cfg.condition_dim = int(condition_dim)
+        cfg.hidden_dim = int(hidden_dim)
+        cfg.depth = int(depth)
+        cfg.num_heads = int(num_heads)
+        cfg.mlp_hidden = int(mlp_hidden)
+        cfg.freq_dim = int(freq_dim)
+        cfg.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        self.mode = cfg.mode
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib.v4h_plan_create(C.byref(cfg), C.byref(h)), "v4h_plan_create")
+        self.handle = h
+        self.num_params = lib.v4h_plan_num_params(h)
+        self.num_stages = lib.v4h_vit_num_backward_stages(h)
+        self.shapes = []
+        for i in range(self.num_params):
+            r, c = _i32(), _i32()
+            check(lib.v4h_plan_param_shape(h, i, C.byref(r), C.byref(c)), "v4h_plan_param_shape")
+            self.shapes.append((r.value,) if c.value == 0 else (r.value, c.value))
+
+    def workspace_bytes(self, B, training):
+        return int(load().v4h_plan_workspace_bytes(self.handle, int(B), 1 if training else 0))
+
+    def __del__(self):
+        try:
+            if _lib is not None and getattr(self, "handle", None):
+                _lib.v4h_plan_destroy(self.handle)
+        except Exception:
+            pass

@@ -1,0 +1,115 @@
+"""One autograd node for the whole ViT: forward and backward both run inside libvit4hep_hip.so."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _vox_shape(net, B):
+    shape, _ = net.geometry()
+    return (B, 1, *shape)
+
+
+def _patchify(net, vox):
+    plan = net._get_plan()
+    B = vox.shape[0]
+    tok = torch.empty((B, net.num_tokens, int(net.patch_dim)), dtype=torch.float32, device=vox.device)
+    _lib.check(_lib.load().v4h_op_patchify(plan.handle, _lib.ptr(vox), _lib.ptr(tok), B, _lib.stream_ptr(vox.device)), "v4h_op_patchify")
+    return tok
+
+
+def _unpatchify(net, tok):
+    plan = net._get_plan()
+    B = tok.shape[0]
+    vox = torch.empty(_vox_shape(net, B), dtype=torch.float32, device=tok.device)
+    _lib.check(_lib.load().v4h_op_unpatchify(plan.handle, _lib.ptr(tok), _lib.ptr(vox), B, _lib.stream_ptr(tok.device)), "v4h_op_unpatchify")
+    return vox
+
+
+def run_forward(net, params, x_vox, t, c, training, ws=None):
+    """Enqueue CaloChallengeCFM.forward on voxels.  Returns (out_vox, workspace)."""
+    plan = net._get_plan()
+    B = x_vox.shape[0]
+    dev = x_vox.device
+    if ws is None:
+        ws = torch.empty(plan.workspace_bytes(B, training), dtype=torch.uint8, device=dev) if training else net.inference_workspace(B, dev)
+    out = torch.empty_like(x_vox)
+    tab = _lib.pointer_table(params)
+    _lib.check(
+        _lib.load().v4h_vit_forward(plan.handle, B, tab, _lib.ptr(x_vox), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                    1 if training else 0, _lib.stream_ptr(dev)),
+        "v4h_vit_forward",
+    )
+    return out, ws
+
+
+def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=None):
+    plan = net._get_plan()
+    B = dout_vox.shape[0] if dout_vox is not None else None
+    if stage_last is None:
+        stage_last = plan.num_stages - 1
+    _lib.check(
+        _lib.load().v4h_vit_backward(plan.handle, B, _lib.pointer_table(params), _lib.pointer_table(grads), _lib.ptr(dout_vox), _lib.ptr(ws), ws.numel(),
+                                     stage_first, stage_last, _lib.stream_ptr(ws.device)),
+        "v4h_vit_backward",
+    )
+
+
+def _prep_inputs(net, x, t, c):
+    x = _lib.require_cuda(x, "x")
+    c = _lib.require_cuda(c, "c")
+    t = _lib.require_cuda(t, "t").reshape(-1)
+    B = x.shape[0]
+    if t.numel() != B or c.shape != (B, int(net.condition_dim)):
+        raise RuntimeError(f"bad conditioning shapes: t {tuple(t.shape)}, c {tuple(c.shape)} for batch {B}")
+    return x, t, c
+
+
+class _ViTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, t, c, patches_io, *params):
+        x_vox = _unpatchify(net, x) if patches_io else x
+        if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):
+            raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {net.geometry()}")
+        training = any(ctx.needs_input_grad[5:])
+        detached = [p.detach() for p in params]
+        out, ws = run_forward(net, detached, x_vox, t, c, training)
+        if training:
+            ctx.net, ctx.ws, ctx.patches_io = net, ws, patches_io
+            ctx.save_for_backward(*params)
+        return _patchify(net, out) if patches_io else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        net = ctx.net
+        params = [p.detach() for p in ctx.saved_tensors]
+        g = _lib.require_cuda(grad_out, "grad_output")
+        dout = _unpatchify(net, g) if ctx.patches_io else g
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]  # 256-byte aligned slices of one zeroed buffer
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dout.device)
+        grads, off = [], 0
+        for p, n in zip(params, sizes):
+            grads.append(flat[off : off + p.numel()].view_as(p))
+            off += n
+        run_backward(net, params, grads, dout, ctx.ws)
+        ctx.ws = None
+        return (None, None, None, None, None, *grads)
+
+
+def vit_apply(net, x, t, c, patches_io):
+    x, t, c = _prep_inputs(net, x, t, c)
+    params = net.parameter_list()
+    for p in params:
+        if not p.is_cuda or p.dtype != torch.float32:
+            raise RuntimeError("vit4hep_amd: parameters must be float32 tensors on the MI355X device (model.to(device, torch.float32))")
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return _ViTFunction.apply(net, x, t, c, patches_io, *params)
+    x_vox = _unpatchify(net, x) if patches_io else x
+    if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):
+        raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {net.geometry()}")
+    out, _ = run_forward(net, [p.detach() for p in params], x_vox, t, c, False)
+    return _patchify(net, out) if patches_io else out

@@ -1,0 +1,380 @@
+// Multi-head self-attention core for the DiT blocks: softmax(q k^T / sqrt(dh)) v, no mask, no dropout
+// (reference nn/vit.py:425-451, both the SDPA and the xformers branch), forward and backward.
+//
+// Data stays token-major exactly as the reference's qkv Linear produces it: qkv[b*T + t][s*D + h*dh + d]
+// (s = 0,1,2 for q,k,v; the reshape (B,N,3,H,dh) of nn/vit.py:427), o[b*T + t][h*dh + d] (nn/vit.py:451).
+//
+// One workgroup = 4 waves works on one (batch, head); each wave owns 16-row tiles of the "lane side" sequence
+// (queries for forward / dQ, keys for dK/dV) and streams the other sequence through LDS in chunks of 160 rows
+// with an online softmax, so T = 135 (ds2) is a single chunk and T = 450 (ds3) three.  Scores are produced
+// with the streamed sequence on the accumulator rows, so a lane holds the scores of ONE lane-side row: the row
+// reductions are in-lane plus two wavefront shuffles (xor 16, 32), and the probability accumulators are re-used
+// directly as the lane-side operand of the next product (frag_from_acc), its other operand being read
+// transposed from the row-major LDS image (ds_read_b64_tr_b16 in bf16 mode).  head_dim 80 is padded to 96 in
+// the contraction by zeroing fragment lanes, never in memory.
+#include "v4h_common.h"
+#include "v4h_gemm.h"  // TileStage
+#include "v4h_ops.h"
+
+namespace {
+
+constexpr int KC = 160;  // streamed rows per LDS chunk (multiple of 32)
+
+template <typename T, int DH> struct AttnCfg {
+  static constexpr int PAD = 16 / (int)sizeof(T);
+  static constexpr int LD = DH + PAD;
+  static constexpr int NKF = (DH + 31) / 32;  // 32-wide contraction slabs over head_dim
+  static constexpr int NDT = DH / 16;         // 16-wide output tiles over head_dim
+  static constexpr int NJT = KC / 16;
+  static constexpr int TILE_ELEMS = KC * LD;
+  static_assert(DH % 16 == 0, "head_dim must be a multiple of 16");
+};
+
+// lane-side fragments of a 16-row tile, straight from global memory (rows >= rows_end and d >= DH read as zero)
+template <typename T, int DH> V4H_DEV void load_row_frags(Frag<T>* f, const T* base, int ld, int row0, int rows_end, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  const int row = row0 + c;
+#pragma unroll
+  for (int s = 0; s < AttnCfg<T, DH>::NKF; ++s) {
+    const int d = 32 * s + 8 * g;
+    f[s] = frag_zero<T>();
+    if (row < rows_end && d + 8 <= DH) {
+      const T* p = base + (size_t)row * ld + d;
+      if constexpr (sizeof(T) == 2) {
+        f[s].v = *reinterpret_cast<const bf16x8*>(p);
+      } else {
+        const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+        f[s].v[0] = a.x; f[s].v[1] = a.y; f[s].v[2] = a.z; f[s].v[3] = a.w;
+        f[s].v[4] = b.x; f[s].v[5] = b.y; f[s].v[6] = b.z; f[s].v[7] = b.w;
+      }
+    }
+  }
+}
+
+// regs-side fragment of streamed rows jt*16.. from the LDS tile, slab s of head_dim, zero beyond DH
+template <typename T, int DH> V4H_DEV Frag<T> tile_frag(const T* tile, int jt, int s, int lane) {
+  Frag<T> f = frag_kcontig(tile, AttnCfg<T, DH>::LD, jt * 16, 32 * s, lane);
+  if (32 * s + 8 * (lane >> 4) + 8 > DH) f = frag_zero<T>();
+  return f;
+}
+
+// acc[jt] (lane: lane-side row c ; regs: streamed row jt*16 + 4g + r) = sum_d X[c][d] * Y[jt*16+4g+r][d]
+template <typename T, int DH> V4H_DEV f32x4 score_tile(const T* tile, int jt, const Frag<T>* x, int lane) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < AttnCfg<T, DH>::NKF; ++s) a = mma(tile_frag<T, DH>(tile, jt, s, lane), x[s], a);
+  return a;
+}
+
+// out[dt] (lane: lane-side row c ; regs: d = dt*16 + 4g + r) += sum_rows W[c][row] * Z[row][d] over the chunk,
+// W given as NJT accumulator tiles, Z the row-major LDS tile read transposed.
+template <typename T, int DH> V4H_DEV void accumulate_wz(f32x4* out, const f32x4* w, const T* ztile, int lane) {
+  using C = AttnCfg<T, DH>;
+#pragma unroll
+  for (int ks = 0; ks < C::NJT / 2; ++ks) {
+    const Frag<T> wf = frag_from_acc(w[2 * ks], w[2 * ks + 1], T());
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      const Frag<T> zf = frag_kstrided2(ztile, C::LD, 32 * ks, 32 * ks + 16, dt * 16, lane);
+      out[dt] = mma(zf, wf, out[dt]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- forward
+template <typename T, int DH> __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+                                                                                      int Tn, int H, float scale) {
+  using C = AttnCfg<T, DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);
+  T* sV = sK + C::TILE_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * DH, ld = 3 * D;
+  const T* base = qkv + (size_t)b * Tn * ld + h * DH;
+  const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
+  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int qt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const bool active = qt < ntiles;  // wave-uniform
+    Frag<T> xq[C::NKF];
+    load_row_frags<T, DH>(xq, base, ld, qt * 16, active ? Tn : 0, lane);
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[C::NDT];
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (!(nchunks == 1 && rd > 0)) {
+        __syncthreads();
+        TileStage<T, KC, DH, C::LD> st;
+        st.load(base + D, ld, ch * KC, 0, Tn, DH, tid);
+        st.store(sK, tid);
+        st.load(base + 2 * D, ld, ch * KC, 0, Tn, DH, tid);
+        st.store(sV, tid);
+        __syncthreads();
+      }
+      if (active) {
+        f32x4 p[C::NJT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < C::NJT; ++jt) {
+          p[jt] = score_tile<T, DH>(sK, jt, xq, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = ch * KC + jt * 16 + 4 * g + r;
+            p[jt][r] = key < Tn ? p[jt][r] * scale : -INFINITY;
+            mx = fmaxf(mx, p[jt][r]);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < C::NJT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[jt][r] = __expf(p[jt][r] - mn);
+            rs += p[jt][r];
+          }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] *= alpha;
+        accumulate_wz<T, DH>(oacc, p, sV, lane);
+      }
+    }
+    const int q = qt * 16 + c;
+    if (active && q < Tn) {
+      const float inv = 1.0f / l;
+      T* orow = o + ((size_t)b * Tn + q) * D + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) store4(orow + dt * 16 + 4 * g, oacc[dt] * inv);
+      if (g == 0 && lse) lse[((size_t)b * H + h) * Tn + q] = m + __logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward
+// delta[b,h,t] = sum_d dO[t][d] * O[t][d]
+template <typename T> __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int BT, int Tn, int H, int DH) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (token, head)
+  if (idx >= BT * H) return;
+  const int tok = idx / H, h = idx % H;
+  const T* po = o + (size_t)tok * H * DH + h * DH;
+  const T* pd = dout + (size_t)tok * H * DH + h * DH;
+  float s = 0.f;
+  for (int d = 0; d < DH; d += 4) {
+    const f32x4 a = load4(po + d), bb = load4(pd + d);
+    s += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+  }
+  const int b = tok / Tn, t = tok % Tn;
+  delta[((size_t)b * H + h) * Tn + t] = s;
+}
+
+// dQ: lane side = queries, streamed = keys (K and V chunks in LDS)
+template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                                         const float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H, float scale) {
+  using C = AttnCfg<T, DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);
+  T* sV = sK + C::TILE_ELEMS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * DH, ld = 3 * D;
+  const T* base = qkv + (size_t)b * Tn * ld + h * DH;
+  const T* dobase = dout + (size_t)b * Tn * D + h * DH;
+  const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
+  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int qt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const bool active = qt < ntiles;
+    const int q = qt * 16 + c;
+    Frag<T> xq[C::NKF], xdo[C::NKF];
+    load_row_frags<T, DH>(xq, base, ld, qt * 16, active ? Tn : 0, lane);
+    load_row_frags<T, DH>(xdo, dobase, D, qt * 16, active ? Tn : 0, lane);
+    float lse_q = 0.f, delta_q = 0.f;
+    if (active && q < Tn) {
+      lse_q = lse[((size_t)b * H + h) * Tn + q];
+      delta_q = delta[((size_t)b * H + h) * Tn + q];
+    }
+    f32x4 dq[C::NDT];
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (!(nchunks == 1 && rd > 0)) {
+        __syncthreads();
+        TileStage<T, KC, DH, C::LD> st;
+        st.load(base + D, ld, ch * KC, 0, Tn, DH, tid);
+        st.store(sK, tid);
+        st.load(base + 2 * D, ld, ch * KC, 0, Tn, DH, tid);
+        st.store(sV, tid);
+        __syncthreads();
+      }
+      if (active) {
+        f32x4 ds[C::NJT];
+#pragma unroll
+        for (int jt = 0; jt < C::NJT; ++jt) {
+          const f32x4 s = score_tile<T, DH>(sK, jt, xq, lane);
+          const f32x4 dp = score_tile<T, DH>(sV, jt, xdo, lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = ch * KC + jt * 16 + 4 * g + r;
+            const float p = (key < Tn && q < Tn) ? __expf(s[r] * scale - lse_q) : 0.f;
+            ds[jt][r] = p * (dp[r] - delta_q) * scale;
+          }
+        }
+        accumulate_wz<T, DH>(dq, ds, sK, lane);
+      }
+    }
+    if (active && q < Tn) {
+      T* row = dqkv + ((size_t)b * Tn + q) * ld + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) store4(row + dt * 16 + 4 * g, dq[dt]);
+    }
+  }
+}
+
+// dK, dV: lane side = keys, streamed = queries (Q and dO chunks + their lse / delta in LDS)
+template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H, float scale) {
+  using C = AttnCfg<T, DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sQ = reinterpret_cast<T*>(smem);
+  T* sDO = sQ + C::TILE_ELEMS;
+  float* sLse = reinterpret_cast<float*>(sDO + C::TILE_ELEMS);
+  float* sDelta = sLse + KC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int D = H * DH, ld = 3 * D;
+  const T* base = qkv + (size_t)b * Tn * ld + h * DH;
+  const T* dobase = dout + (size_t)b * Tn * D + h * DH;
+  const float* lse_bh = lse + ((size_t)b * H + h) * Tn;
+  const float* delta_bh = delta + ((size_t)b * H + h) * Tn;
+  const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
+  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+
+  for (int rd = 0; rd < nrounds; ++rd) {
+    const int kt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const bool active = kt < ntiles;
+    const int key = kt * 16 + c;
+    Frag<T> xk[C::NKF], xv[C::NKF];
+    load_row_frags<T, DH>(xk, base + D, ld, kt * 16, active ? Tn : 0, lane);
+    load_row_frags<T, DH>(xv, base + 2 * D, ld, kt * 16, active ? Tn : 0, lane);
+    f32x4 dk[C::NDT], dv[C::NDT];
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (!(nchunks == 1 && rd > 0)) {
+        __syncthreads();
+        TileStage<T, KC, DH, C::LD> st;
+        st.load(base, ld, ch * KC, 0, Tn, DH, tid);
+        st.store(sQ, tid);
+        st.load(dobase, D, ch * KC, 0, Tn, DH, tid);
+        st.store(sDO, tid);
+        if (tid < KC) {
+          const int qq = ch * KC + tid;
+          sLse[tid] = qq < Tn ? lse_bh[qq] : 0.f;
+          sDelta[tid] = qq < Tn ? delta_bh[qq] : 0.f;
+        }
+        __syncthreads();
+      }
+      if (active) {
+        f32x4 pt[C::NJT], dst[C::NJT];
+#pragma unroll
+        for (int jt = 0; jt < C::NJT; ++jt) {
+          const f32x4 s = score_tile<T, DH>(sQ, jt, xk, lane);
+          const f32x4 dp = score_tile<T, DH>(sDO, jt, xv, lane);
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sLse + jt * 16 + 4 * g);
+          const f32x4 de = *reinterpret_cast<const f32x4*>(sDelta + jt * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = ch * KC + jt * 16 + 4 * g + r;
+            const float p = (qq < Tn && key < Tn) ? __expf(s[r] * scale - ls[r]) : 0.f;
+            pt[jt][r] = p;
+            dst[jt][r] = p * (dp[r] - de[r]) * scale;
+          }
+        }
+        accumulate_wz<T, DH>(dv, pt, sDO, lane);
+        accumulate_wz<T, DH>(dk, dst, sQ, lane);
+      }
+    }
+    if (active && key < Tn) {
+      T* row = dqkv + ((size_t)b * Tn + key) * ld + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        store4(row + D + dt * 16 + 4 * g, dk[dt]);
+        store4(row + 2 * D + dt * 16 + 4 * g, dv[dt]);
+      }
+    }
+  }
+}
+
+template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      v4h_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, bytes, hipGetErrorString(e));
+      return V4H_ERR_HIP;
+    }
+  }
+  return V4H_OK;
+}
+
+template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
+  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80 = 480/6, every shipped shape-CFM config)", DH);
+  using C = AttnCfg<T, 80>;
+  const size_t lds = 2 * (size_t)C::TILE_ELEMS * sizeof(T);
+  int rc = set_lds(attn_fwd_kernel<T, 80>, lds, "attn_fwd");
+  if (rc) return rc;
+  const int ntiles = (Tn + 15) / 16;
+  dim3 grid(B * H, (ntiles + 3) / 4);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, 80>), grid, dim3(256), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
+  V4H_CHECK_LAUNCH("attn_fwd");
+  return V4H_OK;
+}
+
+template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH,
+                                     hipStream_t s) {
+  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80)", DH);
+  using C = AttnCfg<T, 80>;
+  const int BT = B * Tn;
+  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((BT * H + 255) / 256), dim3(256), 0, s, (const T*)o, (const T*)dout, delta, BT, Tn, H, DH);
+  V4H_CHECK_LAUNCH("attn_delta");
+  const float scale = 1.0f / sqrtf((float)DH);
+  const int ntiles = (Tn + 15) / 16;
+  dim3 grid(B * H, (ntiles + 3) / 4);
+  const size_t lds_q = 2 * (size_t)C::TILE_ELEMS * sizeof(T);
+  int rc = set_lds(attn_bwd_dq_kernel<T, 80>, lds_q, "attn_bwd_dq");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80>), grid, dim3(256), lds_q, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  V4H_CHECK_LAUNCH("attn_bwd_dq");
+  const size_t lds_kv = lds_q + 2 * KC * sizeof(float);
+  rc = set_lds(attn_bwd_dkv_kernel<T, 80>, lds_kv, "attn_bwd_dkv");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 80>), grid, dim3(256), lds_kv, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  V4H_CHECK_LAUNCH("attn_bwd_dkv");
+  return V4H_OK;
+}
+
+}  // namespace
+
+namespace v4h {
+int attention_fwd(Mode m, const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
+  return m == MODE_BF16 ? attn_fwd_t<bf16>(qkv, o, lse, B, Tn, H, DH, s) : attn_fwd_t<float>(qkv, o, lse, B, Tn, H, DH, s);
+}
+int attention_bwd(Mode m, const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH, hipStream_t s) {
+  return m == MODE_BF16 ? attn_bwd_t<bf16>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s)
+                        : attn_bwd_t<float>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+}
+}  // namespace v4h

@@ -1,0 +1,194 @@
+// vit4hep_amd - MI355X (gfx950 / CDNA4) device helpers shared by every kernel.
+//
+// One fragment convention for both arithmetic modes, so GEMM / attention kernels are written once:
+//
+//   frag[jj] = X[idx = lane & 15][k = k0 + 8 * (lane >> 4) + jj],   jj = 0..7      (a 16 x 32 slab)
+//
+//   bf16 mode : 8 bf16 in 4 VGPRs, ONE  v_mfma_f32_16x16x32_bf16 per slab pair
+//   f32  mode : 8 f32  in 8 VGPRs, EIGHT v_mfma_f32_16x16x4_f32 (MFMA jj uses element jj of both
+//               operands: k-slot (lane>>4) of MFMA jj is physical k0 + 8*(lane>>4) + jj for A and B
+//               alike, so the contraction is a permutation of the same 32 products; exact f32 FMAs).
+//
+// D = A x B with A = "regs-side" operand (its idx becomes 4 consecutive rows held in the 4
+// accumulator registers) and B = "lane-side" operand (its idx becomes lane & 15):
+//   acc[r] = Out[lane_side_idx = lane & 15][regs_side_idx = 4 * (lane >> 4) + r]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define V4H_DEV __device__ __forceinline__
+#define V4H_LDS __attribute__((address_space(3)))
+
+template <typename T> struct Frag;
+template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<bf16> { bf16x8 v; };
+
+template <typename T> V4H_DEV Frag<T> frag_zero() {
+  Frag<T> f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (T)0.0f;
+  return f;
+}
+
+// acc += regs_side (A) x lane_side (B)
+V4H_DEV f32x4 mma(const Frag<bf16>& regs_side, const Frag<bf16>& lane_side, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(regs_side.v, lane_side.v, acc, 0, 0, 0);
+}
+V4H_DEV f32x4 mma(const Frag<float>& regs_side, const Frag<float>& lane_side, f32x4 acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(regs_side.v[j], lane_side.v[j], acc, 0, 0, 0);
+  return acc;
+}
+
+// ---- fragment loads from LDS ---------------------------------------------------------------------
+// K-contiguous image  tile[idx][k]  (row stride ld elements, ld*sizeof(T) % 16 == 0)
+V4H_DEV Frag<bf16> frag_kcontig(const bf16* tile, int ld, int idx0, int k0, int lane) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(tile + (idx0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+  return f;
+}
+V4H_DEV Frag<float> frag_kcontig(const float* tile, int ld, int idx0, int k0, int lane) {
+  Frag<float> f;
+  const float4* p = reinterpret_cast<const float4*>(tile + (idx0 + (lane & 15)) * ld + k0 + 8 * (lane >> 4));
+  float4 a = p[0], b = p[1];
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+  return f;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4 x 16 block of 16-bit elements; lane i receives column i, row q in element q.  EXEC must be all ones.
+V4H_DEV bf16x4 lds_tr_read(const bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 V4H_LDS*)(p));
+}
+
+// K-strided image  tile[k][idx]  (row stride ld elements).  The two 4-row groups of the slab may come
+// from different row bases (ka for jj 0..3, kb for jj 4..7): this lets a k-permutation chosen by the
+// OTHER operand (e.g. an accumulator re-used as operand) be followed exactly.
+//   frag[jj]   = tile[ka + 4*(lane>>4) + jj    ][idx0 + (lane&15)]   jj = 0..3
+//   frag[4+jj] = tile[kb + 4*(lane>>4) + jj    ][idx0 + (lane&15)]
+V4H_DEV Frag<bf16> frag_kstrided2(const bf16* tile, int ld, int ka, int kb, int idx0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  bf16x4 lo = lds_tr_read(tile + (ka + 4 * g + q) * ld + idx0 + 4 * p);
+  bf16x4 hi = lds_tr_read(tile + (kb + 4 * g + q) * ld + idx0 + 4 * p);
+  Frag<bf16> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+V4H_DEV Frag<float> frag_kstrided2(const float* tile, int ld, int ka, int kb, int idx0, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f.v[j] = tile[(ka + 4 * g + j) * ld + idx0 + c];
+    f.v[4 + j] = tile[(kb + 4 * g + j) * ld + idx0 + c];
+  }
+  return f;
+}
+// canonical slab k0..k0+31: rows k0 + 8g + jj  ==  groups (k0 + 4g' ...) with ka = k0 + 4g, kb = k0 + 4g + 4:
+// expressed through the two-base form by folding the extra 4*g into the bases.
+template <typename T> V4H_DEV Frag<T> frag_kstrided(const T* tile, int ld, int k0, int idx0, int lane) {
+  const int g = lane >> 4;
+  return frag_kstrided2(tile, ld, k0 + 4 * g, k0 + 4 * g + 4, idx0, lane);
+}
+
+// accumulators of two 16-wide tiles (same lane-side idx, regs-side = contraction index of the next product)
+// -> lane-side fragment of the next product.  Physical k of element jj: jj<4 -> tile0 row 4g+jj, else tile1 row 4g+jj-4,
+// which is exactly what frag_kstrided2(ka = base0, kb = base1) reads for the other operand.
+V4H_DEV Frag<float> frag_from_acc(f32x4 a0, f32x4 a1, float) {
+  Frag<float> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = a0[j]; f.v[4 + j] = a1[j]; }
+  return f;
+}
+V4H_DEV Frag<bf16> frag_from_acc(f32x4 a0, f32x4 a1, bf16) {
+  Frag<bf16> f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = (bf16)a0[j]; f.v[4 + j] = (bf16)a1[j]; }
+  return f;
+}
+
+// ---- scalar helpers -------------------------------------------------------------------------------
+V4H_DEV float to_f32(float x) { return x; }
+V4H_DEV float to_f32(bf16 x) { return (float)x; }
+
+V4H_DEV void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+V4H_DEV void store4(bf16* p, f32x4 v) {
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+V4H_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+V4H_DEV f32x4 load4(const bf16* p) {
+  bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (float)o[j];
+  return v;
+}
+
+V4H_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+V4H_DEV float dsilu_f(float x) {
+  const float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+// tanh: accurate libm form in f32 (parity) mode, exp-based form in bf16 mode
+template <typename T> V4H_DEV float tanh_m(float u);
+template <> V4H_DEV float tanh_m<float>(float u) { return tanhf(u); }
+template <> V4H_DEV float tanh_m<bf16>(float u) {
+  const float e = __expf(2.0f * u);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+// nn.GELU(approximate="tanh")  (reference nn/vit.py:314-315)
+template <typename T> V4H_DEV float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanh_m<T>(u));
+}
+template <typename T> V4H_DEV float dgelu_tanh_f(float x) {
+  const float x2 = x * x;
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x2);
+  const float t = tanh_m<T>(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+}
+
+V4H_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+V4H_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+#define V4H_OK 0
+#define V4H_ERR_ARG 1
+#define V4H_ERR_HIP 2
+#define V4H_ERR_UNSUPPORTED 3
+
+void v4h_set_error(const char* fmt, ...);
+#define V4H_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      v4h_set_error(__VA_ARGS__);                \
+      return V4H_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+#define V4H_CHECK_LAUNCH(name)                                            \
+  do {                                                                    \
+    hipError_t e_ = hipGetLastError();                                    \
+    if (e_ != hipSuccess) {                                               \
+      v4h_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return V4H_ERR_HIP;                                                 \
+    }                                                                     \
+  } while (0)

@@ -1,0 +1,502 @@
+// Memory-bound pieces of the ViT-CFM path: patch gather/scatter, positional / timestep embeddings, LayerNorm +
+// adaLN modulate (forward and backward, with the gate backward fused in), weight cast/pad, the CFM trajectory and
+// loss, gradient norm, AdamW and the ODE-solver vector updates.  All HBM-bound: vectorised 16-byte accesses where
+// the layout allows, one wave per LayerNorm row, wavefront-shuffle row reductions, f32 statistics.
+#include "v4h_ops.h"
+
+namespace v4h {
+namespace {
+
+template <typename T> V4H_DEV void st1(T* p, float v) { *p = (T)v; }
+
+// ------------------------------------------------------------------------------------------------ cast / pad
+constexpr int MAX_ITEMS = 48;
+struct CastPadTable {
+  CastPadItem it[MAX_ITEMS];
+  int first_block[MAX_ITEMS + 1];
+  int n;
+};
+
+template <typename T> __global__ void cast_pad_kernel(const CastPadTable tb) {
+  int e = 0;
+  while (e + 1 < tb.n && (int)blockIdx.x >= tb.first_block[e + 1]) ++e;
+  const CastPadItem it = tb.it[e];
+  const long total = (long)it.Rp * it.Cp;
+  T* dst = reinterpret_cast<T*>(it.dst);
+  float* dstf = reinterpret_cast<float*>(it.dst);
+  for (long idx = (long)(blockIdx.x - tb.first_block[e]) * blockDim.x * 4 + threadIdx.x * 4; idx < total;
+       idx += (long)(tb.first_block[e + 1] - tb.first_block[e]) * blockDim.x * 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long k = idx + u;
+      if (k < total) {
+        const int r = (int)(k / it.Cp), c = (int)(k % it.Cp);
+        const float val = (r < it.R && c < it.C) ? it.src[(long)r * it.C + c] : 0.0f;
+        if (it.dst_f32) dstf[k] = val;
+        else dst[k] = (T)val;
+      }
+    }
+  }
+}
+
+__global__ void unpad_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int R, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < R * C) dst[idx] += src[(long)(idx / C) * ld_src + idx % C];
+}
+
+// ------------------------------------------------------------------------------------------------ patching
+// CaloChallengeCFM.to_patches (calochallenge_cfm/model.py:54-60): token n=(li*a+ai)*r+ri, feature f=(pi*p2+pj)*p3+pk.
+// One thread per voxel, voxel index fastest -> coalesced reads; writes land in the token row (<= Ppad apart).
+template <typename T> __global__ void patchify_kernel(const float* __restrict__ vox, T* __restrict__ xp, int B, PatchGeom g, int P, int Ppad) {
+  const long nvox = (long)g.L * g.A * g.R;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * nvox) return;
+  const int b = (int)(idx / nvox);
+  const int v = (int)(idx % nvox);
+  const int x = v % g.R, y = (v / g.R) % g.A, z = v / (g.R * g.A);
+  const int li = z / g.p1, pi = z % g.p1, ai = y / g.p2, pj = y % g.p2, ri = x / g.p3, pk = x % g.p3;
+  const int n = (li * g.a + ai) * g.r + ri, f = (pi * g.p2 + pj) * g.p3 + pk;
+  const int Tn = g.l * g.a * g.r;
+  xp[((long)b * Tn + n) * Ppad + f] = (T)vox[idx];
+}
+template <typename T> __global__ void zero_pad_cols_kernel(T* __restrict__ xp, long rows, int P, int Ppad) {
+  const int w = Ppad - P;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows * w) xp[(idx / w) * Ppad + P + idx % w] = (T)0.0f;
+}
+__global__ void unpatchify_kernel(const float* __restrict__ tok, int ld, float* __restrict__ vox, int B, PatchGeom g, int P) {
+  const long nvox = (long)g.L * g.A * g.R;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * nvox) return;
+  const int b = (int)(idx / nvox);
+  const int v = (int)(idx % nvox);
+  const int x = v % g.R, y = (v / g.R) % g.A, z = v / (g.R * g.A);
+  const int li = z / g.p1, pi = z % g.p1, ai = y / g.p2, pj = y % g.p2, ri = x / g.p3, pk = x % g.p3;
+  const int n = (li * g.a + ai) * g.r + ri, f = (pi * g.p2 + pj) * g.p3 + pk;
+  const int Tn = g.l * g.a * g.r;
+  vox[idx] = tok[((long)b * Tn + n) * ld + f];
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings
+// ViT.learnable_pos_embedding (nn/vit.py:156-162) with create_meshgrid buffers (nn/vit.py:137-154), single segment:
+// pe[n] = [sin(px w), cos(px w), sin(py w), cos(py w), sin(pz w), cos(pz w)], w = 2 pi freqs, each D/6 wide.
+__global__ void pos_embed_fwd_kernel(const float* __restrict__ freqs, float* __restrict__ pe, PatchGeom g, int D) {
+  const int nf = D / 6;
+  const int Tn = g.l * g.a * g.r;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Tn * 3 * nf) return;
+  const int n = idx / (3 * nf), rem = idx % (3 * nf), axis = rem / nf, j = rem % nf;
+  const int ri = n % g.r, ai = (n / g.r) % g.a, li = n / (g.r * g.a);
+  const float pos = axis == 0 ? (float)ri / (float)g.r : (axis == 1 ? (float)ai / (float)g.a : (float)li / (float)g.l);
+  const float w = freqs[j] * 6.283185307179586f;
+  const float arg = pos * w;
+  pe[(long)n * D + axis * 2 * nf + j] = sinf(arg);
+  pe[(long)n * D + axis * 2 * nf + nf + j] = cosf(arg);
+}
+// stage 1: G[n][d] = sum_b dx0[b][n][d]   (coalesced over d)
+template <typename T> __global__ void sum_over_batch_kernel(const T* __restrict__ dx0, float* __restrict__ G, int B, int TD) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= TD) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += to_f32(dx0[(long)b * TD + idx]);
+  G[idx] = s;
+}
+// stage 2: dfreqs[j] += 2 pi sum_n sum_axis pos * (G_sin * cos(arg) - G_cos * sin(arg)); one block per j
+__global__ void pos_embed_bwd_kernel(const float* __restrict__ G, const float* __restrict__ freqs, float* __restrict__ dfreqs, PatchGeom g, int D) {
+  const int nf = D / 6;
+  const int j = blockIdx.x;
+  const int Tn = g.l * g.a * g.r;
+  const float w = freqs[j] * 6.283185307179586f;
+  float s = 0.f;
+  for (int n = threadIdx.x; n < Tn; n += blockDim.x) {
+    const int ri = n % g.r, ai = (n / g.r) % g.a, li = n / (g.r * g.a);
+    const float pos[3] = {(float)ri / (float)g.r, (float)ai / (float)g.a, (float)li / (float)g.l};
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+      const float arg = pos[axis] * w;
+      const float gs = G[(long)n * D + axis * 2 * nf + j], gc = G[(long)n * D + axis * 2 * nf + nf + j];
+      s += pos[axis] * (gs * cosf(arg) - gc * sinf(arg));
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) tot += red[w2];
+    atomicAdd(dfreqs + j, tot * 6.283185307179586f);
+  }
+}
+// TimestepEmbedder.timestep_embedding (nn/vit.py:368-389): [cos(t f_i), sin(t f_i)], f_i = exp(-ln(1e4) i / half)
+template <typename T> __global__ void timestep_embed_kernel(const float* __restrict__ t, T* __restrict__ out, int B, int F) {
+  const int half = F / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx % half;
+  const float f = expf(-9.210340371976184f * (float)i / (float)half);
+  const float arg = t[b] * f;
+  out[(long)b * F + i] = (T)cosf(arg);
+  out[(long)b * F + half + i] = (T)sinf(arg);
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm + modulate
+// nn.LayerNorm(D, elementwise_affine=False, eps=1e-6) then modulate (nn/vit.py:309,457-458).  One wave per token row;
+// lane owns float4 groups lane*4 + 256*n.  Two-pass statistics in registers.
+constexpr int LN_MAXV = 4;  // D <= 1024
+template <typename T> __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                                                     const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
+                                                                                     float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;
+  const int b = row / Tn;
+  const float* xr = x + (long)row * D;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < LN_MAXV; ++n) {
+    const int c = lane * 4 + 256 * n;
+    v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      v[n] = load4(xr + c);
+      s += v[n][0] + v[n][1] + v[n][2] + v[n][3];
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int n = 0; n < LN_MAXV; ++n) {
+    const int c = lane * 4 + 256 * n;
+    if (c < D) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = v[n][r] - mu;
+        q += d * d;
+      }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int n = 0; n < LN_MAXV; ++n) {
+    const int c = lane * 4 + 256 * n;
+    if (c < D) {
+      const f32x4 sh = load4(shift + (long)b * ld_mod + c), sc = load4(scale + (long)b * ld_mod + c);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (v[n][r] - mu) * rs * (1.0f + sc[r]) + sh[r];
+      store4(u + (long)row * D + c, o);
+    }
+  }
+}
+
+// Backward of LN+modulate fused with the gate backward of the branch below.  Grid (chunks, B): a workgroup owns
+// ROWS_PER_WG consecutive tokens of ONE sample, so the per-sample sums (dshift, dscale, dgate) are reduced in
+// registers -> LDS -> one f32 atomic per feature per workgroup.
+constexpr int LNB_ROWS = 48;
+template <typename T> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * LNB_ROWS;
+  const int t1 = min(a.T, t0 + LNB_ROWS);
+  const int D = a.D;
+  const T* du = reinterpret_cast<const T*>(a.du);
+  const T* y = reinterpret_cast<const T*>(a.y);
+  f32x4 acc_sh[LN_MAXV], acc_sc[LN_MAXV], acc_g[LN_MAXV], sc[LN_MAXV], gt[LN_MAXV];
+#pragma unroll
+  for (int n = 0; n < LN_MAXV; ++n) {
+    const int c = lane * 4 + 256 * n;
+    acc_sh[n] = acc_sc[n] = acc_g[n] = sc[n] = gt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) {
+      sc[n] = load4(a.scale + (long)b * a.ld_mod + c);
+      if (y) gt[n] = load4(a.gate + (long)b * a.ld_mod_gate + c);
+    }
+  }
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const long row = (long)b * a.T + t;
+    const float mu = a.mean[row], rs = a.rstd[row];
+    f32x4 gy[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int n = 0; n < LN_MAXV; ++n) {
+      const int c = lane * 4 + 256 * n;
+      gy[n] = xh[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < D) {
+        const f32x4 d = load4(du + row * D + c);
+        const f32x4 xv = load4(a.x + row * D + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          xh[n][r] = (xv[r] - mu) * rs;
+          gy[n][r] = d[r] * (1.0f + sc[n][r]);
+          acc_sh[n][r] += d[r];
+          acc_sc[n][r] += d[r] * xh[n][r];
+          s1 += gy[n][r];
+          s2 += gy[n][r] * xh[n][r];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int n = 0; n < LN_MAXV; ++n) {
+      const int c = lane * 4 + 256 * n;
+      if (c < D) {
+        f32x4 dx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dx[r] = rs * (gy[n][r] - s1 - xh[n][r] * s2);
+        if (a.dx_in) dx += load4(a.dx_in + row * D + c);
+        if (a.dx_out) store4(a.dx_out + row * D + c, dx);
+        if (a.dx_out_t) store4(reinterpret_cast<T*>(a.dx_out_t) + row * D + c, dx);
+        if (y) {
+          const f32x4 yv = load4(y + row * D + c);
+          acc_g[n] += dx * yv;
+          store4(reinterpret_cast<T*>(a.dy) + row * D + c, dx * gt[n]);
+        }
+      }
+    }
+  }
+  // cross-wave reduction through LDS, then one atomic per feature
+  __shared__ float red[3][4][LN_MAXV * 256];
+#pragma unroll
+  for (int n = 0; n < LN_MAXV; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = lane * 4 + 256 * n + r;
+      red[0][wave][c] = acc_sh[n][r];
+      red[1][wave][c] = acc_sc[n][r];
+      red[2][wave][c] = acc_g[n][r];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float v0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float v1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(a.dshift + (long)b * a.ld_dmod + c, v0);
+    atomicAdd(a.dscale + (long)b * a.ld_dmod + c, v1);
+    if (y) {
+      const float v2 = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+      atomicAdd(a.dgate + (long)b * a.ld_dgate + c, v2);
+    }
+  }
+}
+
+template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pre, T* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (T)(ds[i] * dsilu_f(pre[i]));
+}
+
+// ------------------------------------------------------------------------------------------------ CFM step
+// linear_trajectory (models/trajectories.py:5-8) as used by CFM._batch_loss (models/base_model.py:209-215)
+__global__ void cfm_prepare_kernel(const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ t, float* __restrict__ xt,
+                                   float* __restrict__ target, int B, int per) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * per) return;
+  const float tt = t[i / per];
+  const float a = x0[i], b = x1[i];
+  xt[i] = (1.0f - tt) * a + tt * b;
+  target[i] = b - a;
+}
+// loss = mean((v - target)^2) (models/base_model.py:217-218) and dv = 2 (v - target) / n
+__global__ void mse_kernel(const float* __restrict__ v, const float* __restrict__ target, float* __restrict__ loss, float* __restrict__ dv, long n, float inv_n) {
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float d = v[i] - target[i];
+    s += d * d;
+    if (dv) dv[i] = 2.0f * d * inv_n;
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+__global__ void sq_norm_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  float s = 0.f;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = load4(g + 4 * i);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) {
+    const float v = g[4 * n4 + threadIdx.x];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+// clip_grad_norm_ + torch.optim.AdamW single tensor (base_experiment.py:573-592; A12 of SURVEY.md):
+// coef = min(1, clip / (norm + 1e-6)); p *= 1 - lr wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+  float coef = 1.0f;
+  if (gnorm_sq) {
+    const float nrm = sqrtf(*gnorm_sq);
+    if (!isfinite(nrm)) return;  // error_if_nonfinite: leave the state untouched, the host raises (CFMTrainer.check_finite)
+    coef = fminf(1.0f, clip / (nrm + 1e-6f));
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] * b1 + (1.0f - b1) * gi;
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+__global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = alpha * a[i] + beta * b[i];
+}
+// torchdiffeq 'rk4' (3/8 rule) final combination: y += h (k1 + 3 (k2 + k3) + k4) / 8
+__global__ void rk4_combine_kernel(float* __restrict__ y, const float* __restrict__ k1, const float* __restrict__ k2, const float* __restrict__ k3,
+                                   const float* __restrict__ k4, float h, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] += (k1[i] + 3.0f * (k2[i] + k3[i]) + k4[i]) * (h * 0.125f);
+}
+
+inline int nblocks(long n, int per_block, int cap = 2048) {
+  long b = (n + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+// ================================================================================================ host wrappers
+int cast_pad_many(Mode m, const CastPadItem* items, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += MAX_ITEMS) {
+    CastPadTable tb;
+    tb.n = (n - base) < MAX_ITEMS ? (n - base) : MAX_ITEMS;
+    int nb = 0;
+    for (int e = 0; e < tb.n; ++e) {
+      tb.it[e] = items[base + e];
+      tb.first_block[e] = nb;
+      const long total = (long)tb.it[e].Rp * tb.it[e].Cp;
+      V4H_CHECK_ARG(total > 0, "cast_pad: empty item %d", base + e);
+      nb += nblocks(total, 1024, 256);
+    }
+    tb.first_block[tb.n] = nb;
+    if (m == MODE_BF16) hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(nb), dim3(256), 0, s, tb);
+    else hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(nb), dim3(256), 0, s, tb);
+    V4H_CHECK_LAUNCH("cast_pad");
+  }
+  return V4H_OK;
+}
+int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_t s) {
+  hipLaunchKernelGGL(unpad_kernel, dim3((R * C + 255) / 256), dim3(256), 0, s, src, ld_src, dst, R, C);
+  V4H_CHECK_LAUNCH("unpad");
+  return V4H_OK;
+}
+int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s) {
+  const long n = (long)B * g.L * g.A * g.R;
+  const long rows = (long)B * g.l * g.a * g.r;
+  const int nb = (int)((n + 255) / 256);
+  if (m == MODE_BF16) hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(nb), dim3(256), 0, s, vox, (bf16*)xp, B, g, P, Ppad);
+  else hipLaunchKernelGGL(patchify_kernel<float>, dim3(nb), dim3(256), 0, s, vox, (float*)xp, B, g, P, Ppad);
+  V4H_CHECK_LAUNCH("patchify");
+  if (Ppad > P) {
+    const int nbz = (int)((rows * (Ppad - P) + 255) / 256);
+    if (m == MODE_BF16) hipLaunchKernelGGL(zero_pad_cols_kernel<bf16>, dim3(nbz), dim3(256), 0, s, (bf16*)xp, rows, P, Ppad);
+    else hipLaunchKernelGGL(zero_pad_cols_kernel<float>, dim3(nbz), dim3(256), 0, s, (float*)xp, rows, P, Ppad);
+    V4H_CHECK_LAUNCH("patchify/pad");
+  }
+  return V4H_OK;
+}
+int unpatchify_f32(const float* tok, int ld, float* vox, int B, const PatchGeom& g, int P, hipStream_t s) {
+  const long n = (long)B * g.L * g.A * g.R;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, tok, ld, vox, B, g, P);
+  V4H_CHECK_LAUNCH("unpatchify");
+  return V4H_OK;
+}
+int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipStream_t s) {
+  V4H_CHECK_ARG(D % 6 == 0, "pos_embed: hidden_dim %d not divisible by 6", D);
+  const int n = g.l * g.a * g.r * 3 * (D / 6);
+  hipLaunchKernelGGL(pos_embed_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, freqs, pe, g, D);
+  V4H_CHECK_LAUNCH("pos_embed_fwd");
+  return V4H_OK;
+}
+int pos_embed_bwd(Mode m, const void* dx0, const float* freqs, float* dfreqs, float* scratch, int B, const PatchGeom& g, int D, hipStream_t s) {
+  const int TD = g.l * g.a * g.r * D;
+  if (m == MODE_BF16) hipLaunchKernelGGL(sum_over_batch_kernel<bf16>, dim3((TD + 255) / 256), dim3(256), 0, s, (const bf16*)dx0, scratch, B, TD);
+  else hipLaunchKernelGGL(sum_over_batch_kernel<float>, dim3((TD + 255) / 256), dim3(256), 0, s, (const float*)dx0, scratch, B, TD);
+  V4H_CHECK_LAUNCH("pos_embed_bwd/sum");
+  hipLaunchKernelGGL(pos_embed_bwd_kernel, dim3(D / 6), dim3(256), 0, s, scratch, freqs, dfreqs, g, D);
+  V4H_CHECK_LAUNCH("pos_embed_bwd");
+  return V4H_OK;
+}
+int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t s) {
+  V4H_CHECK_ARG(F % 2 == 0, "timestep_embed: odd frequency_embedding_size %d", F);
+  const int n = B * (F / 2);
+  if (m == MODE_BF16) hipLaunchKernelGGL(timestep_embed_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t, (bf16*)out, B, F);
+  else hipLaunchKernelGGL(timestep_embed_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t, (float*)out, B, F);
+  V4H_CHECK_LAUNCH("timestep_embed");
+  return V4H_OK;
+}
+int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
+                    hipStream_t s) {
+  V4H_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "ln_modulate: hidden_dim %d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
+  const dim3 grid((BT + 3) / 4);
+  if (m == MODE_BF16) hipLaunchKernelGGL(ln_modulate_fwd_kernel<bf16>, grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
+  else hipLaunchKernelGGL(ln_modulate_fwd_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+  V4H_CHECK_LAUNCH("ln_modulate_fwd");
+  return V4H_OK;
+}
+int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
+  V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 256 * LN_MAXV, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
+  const dim3 grid((a.T + LNB_ROWS - 1) / LNB_ROWS, a.B);
+  if (m == MODE_BF16) hipLaunchKernelGGL(ln_modulate_bwd_kernel<bf16>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(ln_modulate_bwd_kernel<float>, grid, dim3(256), 0, s, a);
+  V4H_CHECK_LAUNCH("ln_modulate_bwd");
+  return V4H_OK;
+}
+int silu_bwd(Mode m, const float* dsilu, const float* pre, void* out, int n, hipStream_t s) {
+  if (m == MODE_BF16) hipLaunchKernelGGL(silu_bwd_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, dsilu, pre, (bf16*)out, n);
+  else hipLaunchKernelGGL(silu_bwd_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, dsilu, pre, (float*)out, n);
+  V4H_CHECK_LAUNCH("silu_bwd");
+  return V4H_OK;
+}
+int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per, hipStream_t s) {
+  const long n = (long)B * per;
+  hipLaunchKernelGGL(cfm_prepare_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x1, x0, t, xt, target, B, per);
+  V4H_CHECK_LAUNCH("cfm_prepare");
+  return V4H_OK;
+}
+int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+  if (e != hipSuccess) { v4h_set_error("mse: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+  hipLaunchKernelGGL(mse_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, v, target, loss, dv, n, 1.0f / (float)n);
+  V4H_CHECK_LAUNCH("mse");
+  return V4H_OK;
+}
+int sq_norm_accum(const float* g, long n, float* out, hipStream_t s) {
+  V4H_CHECK_ARG(((uintptr_t)g % 16) == 0, "sq_norm: gradient buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(sq_norm_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, g, n, out);
+  V4H_CHECK_LAUNCH("sq_norm");
+  return V4H_OK;
+}
+int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
+               float bc1, float bc2, hipStream_t s) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+  V4H_CHECK_LAUNCH("adamw");
+  return V4H_OK;
+}
+int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s) {
+  hipLaunchKernelGGL(axpby_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, out, a, b, alpha, beta, n);
+  V4H_CHECK_LAUNCH("axpby");
+  return V4H_OK;
+}
+int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s) {
+  hipLaunchKernelGGL(rk4_combine_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, y, k1, k2, k3, k4, h, n);
+  V4H_CHECK_LAUNCH("rk4_combine");
+  return V4H_OK;
+}
+
+}  // namespace v4h

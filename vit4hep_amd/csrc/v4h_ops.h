@@ -1,0 +1,65 @@
+// Internal C++ interface between the kernel translation units and the runtime (v4h_runtime.hip).
+// Everything here takes raw device pointers + a hipStream_t; the public C ABI is include/vit4hep_hip.h.
+#pragma once
+#include "v4h_gemm.h"
+
+namespace v4h {
+
+enum Mode : int { MODE_F32 = 0, MODE_BF16 = 1 };
+inline size_t esize(Mode m) { return m == MODE_BF16 ? 2 : 4; }
+
+// ---- contractions (v4h_gemm.hip) ----
+int gemm_fwd(Mode m, int epi, const GemmArgs& a, hipStream_t s);              // P contig, Q contig
+int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s);            // P contig, Q K-strided
+int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s);         // both K-strided, f32 atomics (+ colsum)
+
+// ---- attention (v4h_attention.hip) ----
+int attention_fwd(Mode m, const void* qkv, void* o, float* lse, int B, int T, int H, int DH, hipStream_t s);
+int attention_bwd(Mode m, const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int T, int H, int DH,
+                  hipStream_t s);
+
+// ---- element-wise / reductions (v4h_elementwise.hip) ----
+struct CastPadItem { const float* src; void* dst; int R, C, Rp, Cp; int dst_f32; };  // dst[Rp][Cp] (mode type, or f32 if dst_f32) <- zero-padded src[R][C]
+int cast_pad_many(Mode m, const CastPadItem* items, int n, hipStream_t s);
+int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_t s);   // dst[R][C] += src[r][c]
+
+int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s);
+int unpatchify_f32(const float* tok, int ld, float* vox, int B, const PatchGeom& g, int P, hipStream_t s);
+int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipStream_t s);
+int pos_embed_bwd(Mode m, const void* dx0, const float* freqs, float* dfreqs, float* scratch, int B, const PatchGeom& g, int D, hipStream_t s);
+int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t s);
+
+int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
+                    hipStream_t s);
+struct LnBwdArgs {
+  // LayerNorm+modulate backward (reference nn/vit.py:309-311,331-332,457-458)
+  const void* du;       // [BT][D] mode type: grad wrt the modulated output
+  const float* x;       // [BT][D] LayerNorm input
+  const float* mean; const float* rstd;
+  const float* scale;   // mod chunk, row stride ld_mod
+  int ld_mod;
+  const float* dx_in;   // residual-stream grad to add (may be null)
+  float* dx_out;        // f32 (may be null when only dx_out_t is wanted)
+  void* dx_out_t;       // optional copy in mode type
+  float* dshift; float* dscale; int ld_dmod;   // f32 atomics, [B][ld_dmod] chunks
+  // fused gate backward of the branch below (nn/vit.py:331-332): dy = gate * dx_out ; dgate += sum_t dx_out * y
+  const void* y;        // [BT][D] mode type (null -> skip)
+  const float* gate;    // mod chunk (row stride ld_mod_gate)
+  int ld_mod_gate;
+  void* dy;             // [BT][D] mode type
+  float* dgate; int ld_dgate;
+  int B, T, D;
+};
+int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s);
+int silu_bwd(Mode m, const float* dsilu, const float* pre, void* out, int n, hipStream_t s);  // out = dsilu * silu'(pre)
+
+// ---- CFM step pieces ----
+int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per_sample, hipStream_t s);
+int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s);
+int sq_norm_accum(const float* g, long n, float* out, hipStream_t s);  // out[0] += sum g^2 (atomic)
+int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
+               float bc1, float bc2, hipStream_t s);
+int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
+int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
+
+}  // namespace v4h

@@ -1,0 +1,538 @@
+// Host-side runtime of libvit4hep_hip.so: plan (derived sizes + HBM workspace layout), the forward and the staged
+// backward launch sequences of CaloChallengeCFM.forward (calochallenge_cfm/model.py:62-66 -> nn/vit.py:185-206), and the
+// C ABI of include/vit4hep_hip.h.  No device allocation, no synchronisation: everything is enqueued on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/vit4hep_hip.h"
+#include "v4h_ops.h"
+
+using namespace v4h;
+
+// ------------------------------------------------------------------------------------------------ error slot
+static thread_local char g_err[512] = "";
+void v4h_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------ plan
+enum {  // parameter indices in state_dict() order (nn/vit.py:76-132)
+  P_FREQS = 0, P_XW, P_XB, P_C0W, P_C0B, P_C2W, P_C2B, P_T0W, P_T0B, P_T2W, P_T2B, P_BLOCK0,
+  B_QKVW = 0, B_QKVB, B_PROJW, B_PROJB, B_FC1W, B_FC1B, B_FC2W, B_FC2B, B_ADAW, B_ADAB, B_COUNT,
+  F_LINW = 0, F_LINB, F_ADAW, F_ADAB, F_COUNT
+};
+
+struct v4h_plan {
+  v4h_config cfg;
+  Mode mode;
+  int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;
+  PatchGeom pg;
+  std::vector<int> rows, cols;  // per parameter; cols == 0 for 1-D tensors
+  int nparams() const { return (int)rows.size(); }
+  int blk(int i, int k) const { return P_BLOCK0 + B_COUNT * i + k; }
+  int fin(int k) const { return P_BLOCK0 + B_COUNT * depth + k; }
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int32_t v4h_abi_version(void) { return V4H_ABI_VERSION; }
+extern "C" const char* v4h_last_error(void) { return g_err; }
+
+extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) {
+  V4H_CHECK_ARG(c && out, "plan_create: null argument");
+  V4H_CHECK_ARG(c->mode == V4H_MODE_F32 || c->mode == V4H_MODE_BF16, "plan_create: unknown mode %d", c->mode);
+  V4H_CHECK_ARG(c->in_channels == 1, "plan_create: in_channels %d unsupported (every shape-CFM config uses 1)", c->in_channels);
+  for (int k = 0; k < 3; ++k)
+    V4H_CHECK_ARG(c->shape[k] > 0 && c->patch_shape[k] > 0 && c->shape[k] % c->patch_shape[k] == 0,
+                  "Input size (%d) should be divisible by patch size (%d) in axis %d.", c->shape[k], c->patch_shape[k], k);
+  V4H_CHECK_ARG(c->depth >= 1, "plan_create: depth %d", c->depth);
+  V4H_CHECK_ARG(c->hidden_dim % c->num_heads == 0, "dim should be divisible by num_heads");
+  V4H_CHECK_ARG(c->hidden_dim % 96 == 0 || c->hidden_dim % 32 == 0, "plan_create: hidden_dim %d must be a multiple of 32", c->hidden_dim);
+  V4H_CHECK_ARG(c->hidden_dim % 6 == 0, "plan_create: hidden_dim %d must be divisible by 6 (3-D sincos embedding)", c->hidden_dim);
+  V4H_CHECK_ARG(c->hidden_dim / c->num_heads == 80, "plan_create: head_dim %d not built (only 80)", c->hidden_dim / c->num_heads);
+  V4H_CHECK_ARG(c->mlp_hidden % 32 == 0 && c->freq_dim % 32 == 0, "plan_create: mlp_hidden/freq_dim must be multiples of 32");
+  v4h_plan* p = new v4h_plan();
+  p->cfg = *c;
+  p->mode = (Mode)c->mode;
+  p->pg = PatchGeom{c->shape[0], c->shape[1], c->shape[2], c->patch_shape[0], c->patch_shape[1], c->patch_shape[2],
+                    c->shape[0] / c->patch_shape[0], c->shape[1] / c->patch_shape[1], c->shape[2] / c->patch_shape[2]};
+  p->T = p->pg.l * p->pg.a * p->pg.r;
+  p->P = c->patch_shape[0] * c->patch_shape[1] * c->patch_shape[2];
+  p->Ppad = round_up(p->P, 32);
+  p->D = c->hidden_dim;
+  p->H = c->num_heads;
+  p->DH = p->D / p->H;
+  p->M = c->mlp_hidden;
+  p->Kc = c->condition_dim;
+  p->Kcpad = round_up(p->Kc, 32);
+  p->F = c->freq_dim;
+  p->depth = c->depth;
+  auto add = [&](int r, int cc) { p->rows.push_back(r); p->cols.push_back(cc); };
+  const int D = p->D;
+  add(D / 6, 0);
+  add(D, p->P); add(D, 0);
+  add(D, p->Kc); add(D, 0); add(D, D); add(D, 0);
+  add(D, p->F); add(D, 0); add(D, D); add(D, 0);
+  for (int i = 0; i < p->depth; ++i) {
+    add(3 * D, D); add(3 * D, 0); add(D, D); add(D, 0);
+    add(p->M, D); add(p->M, 0); add(D, p->M); add(D, 0);
+    add(6 * D, D); add(6 * D, 0);
+  }
+  add(p->P, D); add(p->P, 0); add(2 * D, D); add(2 * D, 0);
+  *out = p;
+  return V4H_OK;
+}
+extern "C" void v4h_plan_destroy(v4h_plan* p) { delete p; }
+extern "C" int32_t v4h_plan_num_params(const v4h_plan* p) { return p ? p->nparams() : 0; }
+extern "C" int32_t v4h_plan_param_shape(const v4h_plan* p, int32_t i, int32_t* r, int32_t* c) {
+  V4H_CHECK_ARG(p && i >= 0 && i < p->nparams(), "param_shape: bad index %d", i);
+  *r = p->rows[i];
+  *c = p->cols[i];
+  return V4H_OK;
+}
+extern "C" int32_t v4h_vit_num_backward_stages(const v4h_plan* p) { return p ? p->depth + 2 : 0; }
+
+// ------------------------------------------------------------------------------------------------ workspace layout
+struct BlockWS {
+  float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
+  char *u1, *qkv, *o, *y1, *u2, *hpre, *h, *y2;
+};
+struct WS {
+  std::vector<char*> wop;       // operand-typed (cast / padded) weights, null where the f32 parameter itself is used
+  float* linb_pad;
+  char *xp, *temb, *ht, *cpad, *hc, *silu_c, *uf;
+  float *pe, *ht_pre, *hc_pre, *cond, *modf, *meanf, *rstdf;
+  std::vector<float*> mod, X;
+  std::vector<BlockWS> blk;
+  // backward
+  char* zero_begin; size_t zero_bytes;
+  std::vector<float*> dmod;
+  float *dmodf, *dsilu, *gxw, *gc0w, *glin, *glinb;
+  float *dxA, *dxB, *delta, *G;
+  char *dvp, *dy, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dx0_t;
+  size_t total;
+};
+
+static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = base ? base + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const size_t es = esize(p.mode);
+  const size_t BT = (size_t)B * p.T, D = p.D, M = p.M;
+  w.wop.assign(p.nparams(), nullptr);
+  for (int i = 0; i < p.nparams(); ++i) {
+    if (p.cols[i] == 0) continue;
+    int rp = p.rows[i], cp = p.cols[i];
+    bool padded = false;
+    if (i == P_XW) { cp = p.Ppad; padded = true; }
+    if (i == P_C0W) { cp = p.Kcpad; padded = true; }
+    if (i == p.fin(F_LINW)) { rp = p.Ppad; padded = true; }
+    if (p.mode == MODE_BF16 || padded) w.wop[i] = take((size_t)rp * cp * es);
+  }
+  w.linb_pad = (float*)take(p.Ppad * 4);
+  w.xp = take(BT * p.Ppad * es);
+  w.pe = (float*)take((size_t)p.T * D * 4);
+  w.temb = take((size_t)B * p.F * es);
+  w.ht_pre = (float*)take((size_t)B * D * 4);
+  w.ht = take((size_t)B * D * es);
+  w.cpad = take((size_t)B * p.Kcpad * es);
+  w.hc_pre = (float*)take((size_t)B * D * 4);
+  w.hc = take((size_t)B * D * es);
+  w.cond = (float*)take((size_t)B * D * 4);
+  w.silu_c = take((size_t)B * D * es);
+  w.mod.resize(p.depth);
+  for (int i = 0; i < p.depth; ++i) w.mod[i] = (float*)take((size_t)B * 6 * D * 4);
+  w.modf = (float*)take((size_t)B * 2 * D * 4);
+  const int nx = training ? p.depth + 1 : 2;
+  w.X.resize(p.depth + 1);
+  std::vector<float*> xs(nx);
+  for (int i = 0; i < nx; ++i) xs[i] = (float*)take(BT * D * 4);
+  for (int i = 0; i <= p.depth; ++i) w.X[i] = xs[training ? i : (i & 1)];
+  const int nb = training ? p.depth : 1;
+  std::vector<BlockWS> bs(nb);
+  for (int i = 0; i < nb; ++i) {
+    BlockWS& b = bs[i];
+    b.mean1 = (float*)take(BT * 4); b.rstd1 = (float*)take(BT * 4);
+    b.mean2 = (float*)take(BT * 4); b.rstd2 = (float*)take(BT * 4);
+    b.lse = (float*)take((size_t)B * p.H * p.T * 4);
+    b.x_mid = (float*)take(BT * D * 4);
+    b.u1 = take(BT * D * es); b.qkv = take(BT * 3 * D * es); b.o = take(BT * D * es); b.y1 = take(BT * D * es);
+    b.u2 = take(BT * D * es); b.hpre = take(BT * M * es); b.h = take(BT * M * es); b.y2 = take(BT * D * es);
+  }
+  w.blk.resize(p.depth);
+  for (int i = 0; i < p.depth; ++i) w.blk[i] = bs[training ? i : 0];
+  w.meanf = (float*)take(BT * 4);
+  w.rstdf = (float*)take(BT * 4);
+  w.uf = take(BT * D * es);
+  if (training) {
+    w.zero_begin = base ? base + off : nullptr;
+    const size_t z0 = off;
+    w.dmod.resize(p.depth);
+    for (int i = 0; i < p.depth; ++i) w.dmod[i] = (float*)take((size_t)B * 6 * D * 4);
+    w.dmodf = (float*)take((size_t)B * 2 * D * 4);
+    w.dsilu = (float*)take((size_t)B * D * 4);
+    w.gxw = (float*)take((size_t)D * p.Ppad * 4);
+    w.gc0w = (float*)take((size_t)D * p.Kcpad * 4);
+    w.glin = (float*)take((size_t)p.Ppad * D * 4);
+    w.glinb = (float*)take((size_t)p.Ppad * 4);
+    w.zero_bytes = off - z0;
+    w.dxA = (float*)take(BT * D * 4);
+    w.dxB = (float*)take(BT * D * 4);
+    w.delta = (float*)take((size_t)B * p.H * p.T * 4);
+    w.G = (float*)take((size_t)p.T * D * 4);
+    w.dvp = take(BT * p.Ppad * es);
+    w.dy = take(BT * D * es);
+    w.dhpre = take(BT * M * es);
+    w.du = take(BT * D * es);
+    w.dof = take(BT * D * es);
+    w.dqkv = take(BT * 3 * D * es);
+    w.dmod_t = take((size_t)B * 6 * D * es);
+    w.dcond = take((size_t)B * D * es);
+    w.dh_small = take((size_t)B * D * es);
+    w.dx0_t = take(BT * D * es);
+  }
+  w.total = off;
+}
+
+extern "C" size_t v4h_plan_workspace_bytes(const v4h_plan* p, int32_t B, int32_t training) {
+  if (!p || B <= 0) return 0;
+  WS w;
+  layout(*p, B, training != 0, nullptr, w);
+  return w.total;
+}
+
+// ------------------------------------------------------------------------------------------------ helpers
+#define RUN(x)             \
+  do {                     \
+    int rc_ = (x);         \
+    if (rc_) return rc_;   \
+  } while (0)
+
+struct Ctx {
+  const v4h_plan& p;
+  int B;
+  const void* const* params;
+  WS w;
+  hipStream_t s;
+  int BT() const { return B * p.T; }
+  const float* pf(int i) const { return (const float*)params[i]; }
+  const void* W(int i) const { return w.wop[i] ? (const void*)w.wop[i] : params[i]; }  // GEMM-operand view of a weight
+};
+
+static GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int J, int K) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = P; a.ldp = ldp; a.Q = Q; a.ldq = ldq; a.I = I; a.J = J; a.K = K;
+  return a;
+}
+
+static int wgrad_splitk(int I, int J, int K) {
+  const int tiles = ((I + 159) / 160) * ((J + 159) / 160);
+  int sk = (768 + tiles - 1) / tiles;
+  const int maxk = K / 256 > 1 ? K / 256 : 1;
+  if (sk > maxk) sk = maxk;
+  if (sk > 64) sk = 64;
+  return sk < 1 ? 1 : sk;
+}
+// dW[I][J] += dY^T X  (+ db[I] += column sums of dY)
+static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db) {
+  GemmArgs a = gargs(dY, ld_dy, X, ld_x, I, J, K);
+  a.e.out = dW; a.e.ldo = ldo; a.colsum = db;
+  return gemm_wgrad(c.p.mode, a, wgrad_splitk(I, J, K), c.s);
+}
+
+static int check_common(const v4h_plan* p, int B, const void* const* params, void* ws, size_t ws_bytes, bool training, const char* who) {
+  V4H_CHECK_ARG(p != nullptr, "%s: null plan", who);
+  V4H_CHECK_ARG(B > 0, "%s: empty batch (B=%d)", who, B);
+  V4H_CHECK_ARG(params != nullptr && ws != nullptr, "%s: null parameter table / workspace", who);
+  V4H_CHECK_ARG(((uintptr_t)ws % 256) == 0, "%s: workspace must be 256-byte aligned", who);
+  const size_t need = v4h_plan_workspace_bytes(p, B, training);
+  V4H_CHECK_ARG(ws_bytes >= need, "%s: workspace too small (%zu < %zu bytes)", who, ws_bytes, need);
+  for (int i = 0; i < p->nparams(); ++i) V4H_CHECK_ARG(params[i] != nullptr && ((uintptr_t)params[i] % 16) == 0, "%s: parameter %d null or not 16-byte aligned", who, i);
+  return V4H_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* const* params, const float* x, const float* t, const float* cnd, float* out,
+                                   void* ws, size_t ws_bytes, int32_t training, void* stream) {
+  RUN(check_common(p, B, params, ws, ws_bytes, training != 0, "vit_forward"));
+  V4H_CHECK_ARG(x && t && cnd && out, "vit_forward: null tensor");
+  Ctx c{*p, B, params, WS(), (hipStream_t)stream};
+  layout(*p, B, training != 0, (char*)ws, c.w);
+  const WS& w = c.w;
+  const Mode m = p->mode;
+  const int BT = c.BT(), D = p->D, M = p->M, T = p->T;
+
+  // 0. operand copies of the weights (cast to bf16 / zero-pad awkward extents), padded condition vector
+  {
+    std::vector<CastPadItem> items;
+    for (int i = 0; i < p->nparams(); ++i) {
+      if (!w.wop[i]) continue;
+      int rp = p->rows[i], cp = p->cols[i];
+      if (i == P_XW) cp = p->Ppad;
+      if (i == P_C0W) cp = p->Kcpad;
+      if (i == p->fin(F_LINW)) rp = p->Ppad;
+      items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
+    }
+    items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
+    items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
+    RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
+  }
+  // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
+  RUN(patchify(m, x, w.xp, B, p->pg, p->P, p->Ppad, c.s));
+  RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
+  {
+    GemmArgs a = gargs(w.xp, p->Ppad, c.W(P_XW), p->Ppad, BT, D, p->Ppad);
+    a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T;
+    RUN(gemm_fwd(m, EPI_EMBED, a, c.s));
+  }
+  // 4-8. t_embedder, c_embedder, cond = t_emb + c_emb, silu(cond) (nn/vit.py:197-199)
+  RUN(timestep_embed(m, t, w.temb, B, p->F, c.s));
+  {
+    GemmArgs a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
+    a.e.out = w.ht; a.e.ldo = D; a.e.out2 = w.ht_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_T0B);
+    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+    a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
+    a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B);
+    RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
+    a = gargs(w.cpad, p->Kcpad, c.W(P_C0W), p->Kcpad, B, D, p->Kcpad);
+    a.e.out = w.hc; a.e.ldo = D; a.e.out2 = w.hc_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_C0B);
+    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+    a = gargs(w.hc, D, c.W(P_C2W), D, B, D, D);
+    a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B); a.e.resid = w.cond; a.e.ld_resid = D;
+    RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
+  }
+  // 9. every adaLN modulation of the step (nn/vit.py:323-330, 345-348)
+  for (int i = 0; i <= p->depth; ++i) {
+    const bool last = i == p->depth;
+    const int J = last ? 2 * D : 6 * D;
+    GemmArgs a = gargs(w.silu_c, D, c.W(last ? p->fin(F_ADAW) : p->blk(i, B_ADAW)), D, B, J, D);
+    a.e.out = last ? w.modf : w.mod[i]; a.e.ldo = J; a.e.bias = c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB));
+    RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
+  }
+  // 10. DiT blocks (nn/vit.py:327-333)
+  for (int i = 0; i < p->depth; ++i) {
+    const BlockWS& b = w.blk[i];
+    const float* mod = w.mod[i];
+    RUN(ln_modulate_fwd(m, w.X[i], mod, mod + D, 6 * D, b.u1, b.mean1, b.rstd1, BT, T, D, c.s));
+    GemmArgs a = gargs(b.u1, D, c.W(p->blk(i, B_QKVW)), D, BT, 3 * D, D);
+    a.e.out = b.qkv; a.e.ldo = 3 * D; a.e.bias = c.pf(p->blk(i, B_QKVB));
+    RUN(gemm_fwd(m, EPI_STORE, a, c.s));
+    RUN(attention_fwd(m, b.qkv, b.o, b.lse, B, T, p->H, p->DH, c.s));
+    a = gargs(b.o, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
+    a.e.out = b.x_mid; a.e.ldo = D; a.e.out2 = training ? b.y1 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_PROJB));
+    a.e.rowvec = mod + 2 * D; a.e.ld_rowvec = 6 * D; a.e.T = T; a.e.resid = w.X[i]; a.e.ld_resid = D;
+    RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
+    RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, 6 * D, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
+    a = gargs(b.u2, D, c.W(p->blk(i, B_FC1W)), D, BT, M, D);
+    a.e.out = b.hpre; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M; a.e.bias = c.pf(p->blk(i, B_FC1B));
+    RUN(gemm_fwd(m, EPI_GELU, a, c.s));
+    a = gargs(b.h, M, c.W(p->blk(i, B_FC2W)), M, BT, D, M);
+    a.e.out = w.X[i + 1]; a.e.ldo = D; a.e.out2 = training ? b.y2 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_FC2B));
+    a.e.rowvec = mod + 5 * D; a.e.ld_rowvec = 6 * D; a.e.T = T; a.e.resid = b.x_mid; a.e.ld_resid = D;
+    RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
+  }
+  // 11. FinalLayer (nn/vit.py:347-351) with from_patches fused into the store
+  RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, 2 * D, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
+  {
+    GemmArgs a = gargs(w.uf, D, c.W(p->fin(F_LINW)), D, BT, p->Ppad, D);
+    a.e.out = out; a.e.bias = w.linb_pad; a.e.T = T; a.e.pg = p->pg; a.e.P = p->P;
+    RUN(gemm_fwd(m, EPI_UNPATCH, a, c.s));
+  }
+  return V4H_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int bidx, void* const* grads) {
+  const WS& w = c.w;
+  const int D = c.p.D, B = c.B;
+  CastPadItem it{dmod, w.dmod_t, B, J, B, J, 0};
+  RUN(cast_pad_many(c.p.mode, &it, 1, c.s));
+  RUN(wgrad(c, w.dmod_t, J, J, w.silu_c, D, D, B, (float*)grads[widx], D, (float*)grads[bidx]));
+  GemmArgs a = gargs(w.dmod_t, J, c.W(widx), D, B, D, J);
+  a.e.out = w.dsilu; a.e.ldo = D;
+  return gemm_dgrad(c.p.mode, EPI_ACCUM_F32, a, c.s);
+}
+
+extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
+                                    int32_t stage_first, int32_t stage_last, void* stream) {
+  RUN(check_common(p, B, params, ws, ws_bytes, true, "vit_backward"));
+  V4H_CHECK_ARG(grads != nullptr, "vit_backward: null gradient table");
+  for (int i = 0; i < p->nparams(); ++i) V4H_CHECK_ARG(grads[i] != nullptr && ((uintptr_t)grads[i] % 16) == 0, "vit_backward: gradient %d null or not 16-byte aligned", i);
+  const int nst = p->depth + 2;
+  V4H_CHECK_ARG(stage_first >= 0 && stage_last < nst && stage_first <= stage_last, "vit_backward: bad stage range [%d,%d] of %d", stage_first, stage_last, nst);
+  V4H_CHECK_ARG(stage_first > 0 || dout != nullptr, "vit_backward: null output gradient");
+  Ctx c{*p, B, params, WS(), (hipStream_t)stream};
+  layout(*p, B, true, (char*)ws, c.w);
+  const WS& w = c.w;
+  const Mode m = p->mode;
+  const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
+  // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
+  auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
+
+  for (int st = stage_first; st <= stage_last; ++st) {
+    if (st == 0) {
+      hipError_t e = hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, c.s);
+      if (e != hipSuccess) { v4h_set_error("vit_backward: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+      RUN(patchify(m, dout, w.dvp, B, p->pg, p->P, p->Ppad, c.s));
+      RUN(wgrad(c, w.dvp, p->Ppad, p->Ppad, w.uf, D, D, BT, w.glin, D, w.glinb));
+      GemmArgs a = gargs(w.dvp, p->Ppad, c.W(p->fin(F_LINW)), D, BT, D, p->Ppad);
+      a.e.out = w.du; a.e.ldo = D;
+      RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      LnBwdArgs l;
+      memset(&l, 0, sizeof(l));
+      l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = 2 * D;
+      l.dx_out = dxbuf(0); l.dshift = w.dmodf; l.dscale = w.dmodf + D; l.ld_dmod = 2 * D;
+      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[depth - 1] + 5 * D; l.ld_dgate = 6 * D;
+      l.B = B; l.T = T; l.D = D;
+      RUN(ln_modulate_bwd(m, l, c.s));
+      RUN(unpad_f32(w.glin, D, (float*)grads[p->fin(F_LINW)], p->P, D, c.s));
+      RUN(unpad_f32(w.glinb, 1, (float*)grads[p->fin(F_LINB)], p->P, 1, c.s));
+      RUN(adaln_backward(c, w.dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
+    } else if (st <= depth) {
+      const int j = st - 1, i = depth - 1 - j;
+      const BlockWS& b = w.blk[i];
+      float* dx_in = dxbuf(2 * j);        // grad wrt X[i+1]
+      float* dx_mid = dxbuf(2 * j + 1);   // grad wrt x_mid
+      float* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
+      // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
+      RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)]));
+      GemmArgs a = gargs(w.dy, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
+      a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hpre; a.e.ld_aux = M;
+      RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
+      RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)]));
+      a = gargs(w.dhpre, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
+      a.e.out = w.du; a.e.ldo = D;
+      RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      LnBwdArgs l;
+      memset(&l, 0, sizeof(l));
+      l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = 6 * D;
+      l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = w.dmod[i] + 3 * D; l.dscale = w.dmod[i] + 4 * D; l.ld_dmod = 6 * D;
+      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
+      l.B = B; l.T = T; l.D = D;
+      RUN(ln_modulate_bwd(m, l, c.s));
+      // --- attention branch (nn/vit.py:425-454,331) ---
+      RUN(wgrad(c, w.dy, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)]));
+      a = gargs(w.dy, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
+      a.e.out = w.dof; a.e.ldo = D;
+      RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, w.dqkv, B, T, p->H, p->DH, c.s));
+      RUN(wgrad(c, w.dqkv, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)]));
+      a = gargs(w.dqkv, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
+      a.e.out = w.du; a.e.ldo = D;
+      RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      memset(&l, 0, sizeof(l));
+      l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = 6 * D;
+      l.dx_in = dx_mid; l.dshift = w.dmod[i]; l.dscale = w.dmod[i] + D; l.ld_dmod = 6 * D;
+      if (i > 0) {
+        l.dx_out = dx_out;
+        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[i - 1] + 5 * D; l.ld_dgate = 6 * D;
+      } else {
+        l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
+      }
+      l.B = B; l.T = T; l.D = D;
+      RUN(ln_modulate_bwd(m, l, c.s));
+      RUN(adaln_backward(c, w.dmod[i], 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
+    } else {
+      // --- embedders (nn/vit.py:76-82,193-199) ---
+      RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Ppad, p->Ppad, BT, w.gxw, p->Ppad, (float*)grads[P_XB]));
+      RUN(unpad_f32(w.gxw, p->Ppad, (float*)grads[P_XW], D, p->P, c.s));
+      RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
+      RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
+      // c_embedder
+      RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
+      GemmArgs a = gargs(w.dcond, D, c.W(P_C2W), D, B, D, D);
+      a.e.out = w.dh_small; a.e.ldo = D; a.e.auxf = w.hc_pre; a.e.ld_auxf = D;
+      RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
+      RUN(wgrad(c, w.dh_small, D, D, w.cpad, p->Kcpad, p->Kcpad, B, w.gc0w, p->Kcpad, (float*)grads[P_C0B]));
+      RUN(unpad_f32(w.gc0w, p->Kcpad, (float*)grads[P_C0W], D, p->Kc, c.s));
+      // t_embedder
+      RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B]));
+      a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
+      a.e.out = w.dh_small; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
+      RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
+      RUN(wgrad(c, w.dh_small, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B]));
+    }
+  }
+  return V4H_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ CFM step pieces
+extern "C" int32_t v4h_cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int32_t B, int64_t per, void* s) {
+  V4H_CHECK_ARG(x1 && x0 && t && xt && target && B > 0 && per > 0 && per < (1LL << 31), "cfm_prepare: bad argument");
+  return cfm_prepare(x1, x0, t, xt, target, B, (int)per, (hipStream_t)s);
+}
+extern "C" int32_t v4h_mse_loss(const float* v, const float* target, float* loss, float* dv, int64_t n, void* s) {
+  V4H_CHECK_ARG(v && target && loss && n > 0, "mse_loss: bad argument");
+  return mse_fwd_bwd(v, target, loss, dv, n, (hipStream_t)s);
+}
+extern "C" int32_t v4h_sq_norm_accum(const float* g, int64_t n, float* out, void* s) {
+  V4H_CHECK_ARG(g && out && n > 0, "sq_norm_accum: bad argument");
+  return sq_norm_accum(g, n, out, (hipStream_t)s);
+}
+extern "C" int32_t v4h_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr, float b1, float b2,
+                                  float eps, float wd, int32_t step, void* s) {
+  V4H_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad argument");
+  const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  return adamw_step(p, g, m, v, n, gnorm_sq, max_norm, lr, b1, b2, eps, wd, (float)bc1, (float)bc2, (hipStream_t)s);
+}
+extern "C" int32_t v4h_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n, void* s) {
+  V4H_CHECK_ARG(out && a && b && n > 0, "axpby: bad argument");
+  return axpby(out, a, b, alpha, beta, n, (hipStream_t)s);
+}
+extern "C" int32_t v4h_rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, int64_t n, void* s) {
+  V4H_CHECK_ARG(y && k1 && k2 && k3 && k4 && n > 0, "rk4_combine: bad argument");
+  return rk4_combine(y, k1, k2, k3, k4, h, n, (hipStream_t)s);
+}
+
+// ------------------------------------------------------------------------------------------------ single operators
+extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t pks, const void* Q, int32_t ldq, int32_t qks, const float* bias, void* out,
+                               int32_t ldo, int32_t out_f32, int32_t I, int32_t J, int32_t K, int32_t splitk, float* colsum, void* s) {
+  V4H_CHECK_ARG(mode == 0 || mode == 1, "op_gemm: bad mode");
+  V4H_CHECK_ARG(P && Q && out, "op_gemm: null tensor");
+  GemmArgs a = gargs(P, ldp, Q, ldq, I, J, K);
+  a.e.out = out; a.e.ldo = ldo; a.e.bias = bias; a.colsum = colsum;
+  if (!pks && !qks) return gemm_fwd((Mode)mode, out_f32 ? EPI_STORE_F32 : EPI_STORE, a, (hipStream_t)s);
+  if (!pks && qks) return gemm_dgrad((Mode)mode, out_f32 ? EPI_STORE_F32 : EPI_STORE, a, (hipStream_t)s);
+  if (pks && qks) {
+    V4H_CHECK_ARG(out_f32 && !bias, "op_gemm: the wgrad form accumulates into an f32 output without bias");
+    return gemm_wgrad((Mode)mode, a, splitk, (hipStream_t)s);
+  }
+  v4h_set_error("op_gemm: layout (P K-strided, Q K-contiguous) is not used on the path and not built");
+  return V4H_ERR_UNSUPPORTED;
+}
+extern "C" int32_t v4h_op_attention_fwd(int32_t mode, const void* qkv, void* o, float* lse, int32_t B, int32_t T, int32_t H, int32_t dh, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && qkv && o && B > 0 && T > 0 && H > 0, "op_attention_fwd: bad argument");
+  return attention_fwd((Mode)mode, qkv, o, lse, B, T, H, dh, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_attention_bwd(int32_t mode, const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int32_t B,
+                                        int32_t T, int32_t H, int32_t dh, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && qkv && o && dout && lse && delta && dqkv && B > 0 && T > 0 && H > 0, "op_attention_bwd: bad argument");
+  return attention_bwd((Mode)mode, qkv, o, dout, lse, delta, dqkv, B, T, H, dh, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_ln_modulate_fwd(int32_t mode, const float* x, const float* shift, const float* scale, int32_t ld_mod, void* u, float* mean, float* rstd,
+                                          int32_t B, int32_t T, int32_t D, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && x && shift && scale && u && B > 0 && T > 0, "op_ln_modulate_fwd: bad argument");
+  return ln_modulate_fwd((Mode)mode, x, shift, scale, ld_mod, u, mean, rstd, B * T, T, D, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_patchify(const v4h_plan* p, const float* vox, float* tok, int32_t B, void* s) {
+  V4H_CHECK_ARG(p && vox && tok && B > 0, "op_patchify: bad argument");
+  return patchify(MODE_F32, vox, tok, B, p->pg, p->P, p->P, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_unpatchify(const v4h_plan* p, const float* tok, float* vox, int32_t B, void* s) {
+  V4H_CHECK_ARG(p && vox && tok && B > 0, "op_unpatchify: bad argument");
+  return unpatchify_f32(tok, p->P, vox, B, p->pg, p->P, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_pos_embed(const v4h_plan* p, const float* freqs, float* pe, void* s) {
+  V4H_CHECK_ARG(p && freqs && pe, "op_pos_embed: bad argument");
+  return pos_embed_fwd(freqs, pe, p->pg, p->D, (hipStream_t)s);
+}

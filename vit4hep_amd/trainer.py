@@ -1,0 +1,150 @@
+"""Native CFM update step: the semantics of BaseExperiment._step (reference experiments/base_experiment.py:555-602
+with configs/training/default.yaml) on flat HBM buffers, without autograd and without per-step host syncs.
+
+  loss  = CFM._batch_loss                         (models/base_model.py:203-218)   -> HIP forward + fused MSE
+  grads = loss.backward()                         (:560)                           -> staged HIP backward
+  DDP gradient averaging                          (:161-167)                       -> bucketed RCCL all-reduce, overlapped
+  clip_grad_norm_(..., clip, error_if_nonfinite)  (:573-585)                       -> one norm kernel; clip folded into AdamW
+  AdamW(lr, betas, eps, wd) + CosineAnnealingLR   (:592-597, :329-431)             -> one fused kernel over all parameters
+  all_reduce(loss, AVG)                           (:600-601)
+
+Loss and gradient norm come back as 0-dim device tensors; call ``check_finite`` (or .item()) when the host needs them.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .autograd import run_backward, run_forward
+from .parallel import BucketReducer, world
+
+
+def _aligned(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class CFMTrainer:
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None):
+        from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
+
+        self.model = model
+        self.net = _unwrap(model.net)
+        self.net.set_geometry(model.shape, model.patch_shape)
+        self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.clip = float(clip_grad_norm) if clip_grad_norm is not None else None
+        self.iterations = int(iterations)
+        self.step_count = 0
+        self.group = group
+        self._flatten()
+
+    # ---------------------------------------------------------------------------------------------- flat buffers
+    def _flatten(self):
+        params = self.net.parameter_list()
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("CFMTrainer: move the model to the MI355X first (model.to('cuda')); there is no CPU path")
+        self.offsets, off = [], 0
+        for p in params:
+            self.offsets.append(off)
+            off += _aligned(p.numel())
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.p_views, self.g_views = [], []
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                view = self.flat_p[o : o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                self.p_views.append(view)
+                self.g_views.append(self.flat_g[o : o + p.numel()].view_as(p))
+        self.params = params
+        # contiguous gradient slice of each backward stage (include/vit4hep_hip.h: stage 0 final layer, 1+j block depth-1-j, last embedders)
+        depth = int(self.net.depth)
+        blk0 = 11
+        bounds = lambda i0, i1: (self.offsets[i0], self.offsets[i1] if i1 < len(params) else self.total)
+        self.stage_slices = [bounds(blk0 + 10 * depth, len(params))]
+        for j in range(depth):
+            i = depth - 1 - j
+            self.stage_slices.append(bounds(blk0 + 10 * i, blk0 + 10 * (i + 1)))
+        self.stage_slices.append(bounds(0, blk0))
+        self.reducer = BucketReducer(self.flat_g, self.group)
+        self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+
+    def _check_alias(self):
+        if any(p.data_ptr() != v.data_ptr() for p, v in ((self.params[0], self.p_views[0]), (self.params[-1], self.p_views[-1]))):
+            m, v, n = self.flat_m, self.flat_v, self.step_count
+            self._flatten()  # parameters were re-allocated (e.g. model.to(...)): adopt the new storage, keep the optimizer state
+            if m.numel() == self.flat_m.numel() and m.device == self.flat_m.device:
+                self.flat_m, self.flat_v, self.step_count = m, v, n
+
+    def lr_at(self, k):
+        """CosineAnnealingLR(T_max=iterations, eta_min=0) after k scheduler steps (closed form)."""
+        return self.lr * 0.5 * (1.0 + math.cos(math.pi * k / self.iterations))
+
+    # ---------------------------------------------------------------------------------------------- one update
+    def loss_and_grads(self, x, c, t=None, x0=None):
+        """Forward + backward into the flat gradient buffer (all-reduced over the data-parallel group)."""
+        self._check_alias()
+        lib = _lib.load()
+        dev = self.flat_p.device
+        x = _lib.require_cuda(x, "x")
+        c = _lib.require_cuda(c, "c")
+        B = x.shape[0]
+        if t is None:  # reference: CPU generator for t, device generator for x_0 (models/base_model.py:209-212)
+            t = self.model.time_distribution.sample([B] + [1] * (x.dim() - 1)).to(dev, torch.float32, non_blocking=True)
+        if x0 is None:
+            x0 = torch.randn_like(x)
+        t = _lib.require_cuda(t, "t").reshape(-1)
+        x0 = _lib.require_cuda(x0, "x0")
+        s = _lib.stream_ptr(dev)
+        xt, target = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.v4h_cfm_prepare(_lib.ptr(x), _lib.ptr(x0), _lib.ptr(t), _lib.ptr(xt), _lib.ptr(target), B, x[0].numel(), s), "v4h_cfm_prepare")
+        v, ws = run_forward(self.net, self.p_views, xt, t, c, True)
+        dv = torch.empty_like(v)
+        _lib.check(lib.v4h_mse_loss(_lib.ptr(v), _lib.ptr(target), _lib.ptr(self.loss), _lib.ptr(dv), v.numel(), s), "v4h_mse_loss")
+        W = world()
+        if W > 1:  # DDP averages gradients: fold 1/world into the seed, then SUM
+            _lib.check(lib.v4h_axpby(_lib.ptr(dv), _lib.ptr(dv), _lib.ptr(dv), 1.0 / W, 0.0, dv.numel(), s), "v4h_axpby")
+        self.flat_g.zero_()
+        for st, (lo, hi) in enumerate(self.stage_slices):
+            run_backward(self.net, self.p_views, self.g_views, dv, ws, st, st)
+            self.reducer.reduce_slice(lo, hi)
+        self.reducer.finish()
+        return self.loss
+
+    def step(self, x, c, t=None, x0=None):
+        """One BaseExperiment._step.  Returns (loss, grad_norm) as 0-dim device tensors (pre-clip norm, like clip_grad_norm_)."""
+        lib = _lib.load()
+        loss = self.loss_and_grads(x, c, t, x0)
+        s = _lib.stream_ptr(self.flat_p.device)
+        self.gnorm_sq.zero_()
+        _lib.check(lib.v4h_sq_norm_accum(_lib.ptr(self.flat_g), self.total, _lib.ptr(self.gnorm_sq), s), "v4h_sq_norm_accum")
+        self.step_count += 1
+        lr = self.lr_at(self.step_count - 1)
+        _lib.check(
+            lib.v4h_adamw_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
+                               _lib.ptr(self.gnorm_sq) if self.clip is not None else None, self.clip or 0.0, lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                               self.step_count, s),
+            "v4h_adamw_step",
+        )
+        out_loss = loss.clone()
+        if world() > 1:
+            dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
+            out_loss /= world()
+        return out_loss, self.gnorm_sq.sqrt()
+
+    @staticmethod
+    def check_finite(grad_norm):
+        """error_if_nonfinite=True of the reference's clip_grad_norm_ call (base_experiment.py:581); needs a host sync."""
+        g = float(grad_norm)
+        if not math.isfinite(g):
+            raise RuntimeError("The total norm for gradients is non-finite, so it cannot be clipped.")
+        return g
