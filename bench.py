@@ -1,0 +1,226 @@
+"""bench.py - CFM train steps/s of the CaloChallenge-ds2 shape ViT (depth 6, hidden 480, 6 heads, mlp 1920; bs = 128 per GPU)
+on N MI355X, through the HIP path, plus the MFMA roofline fraction and the CPU-oracle baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode bf16|f32] [--workload ds2|ds3|ds2_d2] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one BaseExperiment._step of the reference (experiments/base_experiment.py:555-602) on one synthetic batch per GPU:
+t ~ U(0,1), x0 ~ N(0,1), x_t / target, ViT forward, MSE, backward, gradient all-reduce (N > 1), grad-norm clip(1000), AdamW,
+cosine LR.  Inputs x, c are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+`value` is the whole-job rate in units of bs=128 steps: N * K / time (weak scaling: every GPU keeps 128 samples per step).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector rate
+
+WORKLOADS = {
+    # name: (shape, patch_shape, depth, per-GPU batch, description)
+    "ds2": ((45, 16, 9), (3, 16, 1), 6, 128, "CaloChallenge-ds2 shape CFM, full ViT (depth 6), bs=128 per GPU"),
+    "ds3": ((45, 50, 18), (3, 10, 3), 6, 64, "CaloChallenge-ds3 shape CFM, full ViT (depth 6), bs=64 per GPU"),
+    "ds2_d2": ((45, 16, 9), (3, 16, 1), 2, 8, "CaloChallenge-ds2 shape CFM, ViT depth 2, bs=8 (reference CPU-runnable case)"),
+}
+
+
+def fwd_flops_per_sample(T, P, depth, D=480, M=1920, K=46, F=256):
+    """2*m*n*k of every contraction of one forward, per sample."""
+    return depth * T * (2 * D * 3 * D + 2 * D * D + 4 * D * M + 4 * T * D) + 4 * P * D * T + (depth * 12 * D * D + 4 * D * D + 2 * (K * D + D * D) + 2 * (F * D + D * D))
+
+
+def build_model(shape, patch_shape, depth, mode, device):
+    from vit4hep_amd import CaloChallengeCFM, ViT
+
+    l, a, r = (s // p for s, p in zip(shape, patch_shape))
+    P = patch_shape[0] * patch_shape[1] * patch_shape[2]
+    net = ViT({"dim": 3, "condition_dim": 46, "hidden_dim": 480, "out_channels": 1, "depth": depth, "num_heads": 6, "mlp_ratio": 4, "attn_drop": 0.0,
+               "proj_drop": 0.0, "pos_embedding_coords": "cylindrical", "temperature": 10000, "learn_pos_embed": True, "causal_attn": False,
+               "checkpoint_grads": False, "num_patches": [[l, a, r]], "patch_dim": P, "use_torch_sdpa": False, "amd_mode": mode})
+    model = CaloChallengeCFM(net, list(patch_shape), in_channels=1, time_distribution="uniform", trajectory="linear",
+                             odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=list(shape))
+    # random-init weights of that architecture; the zero-initialised adaLN / output tensors (nn/vit.py:174-183) are given small
+    # random values so the step does the same arithmetic as a model a few hundred iterations into training (no zero operands).
+    g = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "adaLN_modulation" in name or "final_layer.linear" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    model = model.to(device)
+    model.device, model.dtype = torch.device(device), torch.float32
+    return model
+
+
+def synthetic(shape, B, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 1, *shape), generator=g)
+    c = torch.cat([torch.randn((B, 45), generator=g), torch.rand((B, 1), generator=g)], dim=1)
+    return x.to(device), c.to(device)
+
+
+def op_rates(mode, BT, device, reps=20):
+    """Live HIP-event timing of the four block GEMM shapes (forward form) through the C ABI: TFLOP/s each."""
+    from vit4hep_amd import _lib
+
+    lib = _lib.load()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    out = {}
+    for name, (J, K) in {"qkv 480->1440": (1440, 480), "proj 480->480": (480, 480), "fc1 480->1920": (1920, 480), "fc2 1920->480": (480, 1920)}.items():
+        P = torch.randn((BT, K), device=device).to(dt)
+        Q = torch.randn((J, K), device=device).to(dt)
+        o = torch.empty((BT, J), device=device, dtype=dt)
+        s = _lib.stream_ptr(device)
+        args = (_lib.MODES[mode], _lib.ptr(P), K, 0, _lib.ptr(Q), K, 0, None, _lib.ptr(o), J, 0, BT, J, K, 1, None, s)
+        for _ in range(3):
+            _lib.check(lib.v4h_op_gemm(*args))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _lib.check(lib.v4h_op_gemm(*args))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[name] = {"us": round(us, 2), "tflops": round(2.0 * BT * J * K / us / 1e6, 1)}
+    return out
+
+
+def cpu_baseline(shape, patch_shape, depth, B, budget_s=20.0):
+    """The CPU oracle (kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import vit_cfm_oracle as O
+
+    cfg = O.ViTConfig(shape=tuple(shape), patch_shape=tuple(patch_shape), depth=depth)
+    # the GPU box gives one GPU's share of the host: 16 cores (its os.cpu_count() reports the whole machine)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = int(os.environ.get("V4H_CPU_THREADS", min(avail, 16)))
+    torch.set_num_threads(threads)
+    p = O.golden_fill(cfg)
+    st = O.AdamWState()
+    x, c, g = O.synthetic_batch(cfg, B, 0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        t, x0 = O.synthetic_noise(cfg, B, g)
+        O.train_step(p, st, x, c, t, x0, cfg)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": round(n / el, 4), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full update steps of the same workload (B={B}, depth {depth}) with the PyTorch-CPU oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="ds2", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-rates", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} ...")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", device_id=torch.device(device))
+
+    from vit4hep_amd.trainer import CFMTrainer
+
+    shape, patch_shape, depth, B, desc = WORKLOADS[args.workload]
+    model = build_model(shape, patch_shape, depth, args.mode, device)
+    if world > 1:  # same initial weights everywhere, like DDP's constructor broadcast (base_experiment.py:163)
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
+    x, c = synthetic(shape, B, seed=rank, device=device)
+    torch.manual_seed(1000 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss, gn = trainer.step(x, c)
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss, gn = trainer.step(x, c)
+    e1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    CFMTrainer.check_finite(gn)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    if rank == 0:
+        T = (shape[0] // patch_shape[0]) * (shape[1] // patch_shape[1]) * (shape[2] // patch_shape[2])
+        P = patch_shape[0] * patch_shape[1] * patch_shape[2]
+        flop_step = 3.0 * B * fwd_flops_per_sample(T, P, depth)  # per GPU
+        ms_step = wall * 1e3 / args.steps
+        dev_ms_step = dev_ms / args.steps
+        achieved = flop_step / (dev_ms_step * 1e-3) / 1e12
+        peak = BF16_DENSE_PEAK_TFLOPS if args.mode == "bf16" else F32_MFMA_PEAK_TFLOPS
+        rec = {
+            "metric": "CFM train steps/sec (ds2 shape ViT, bs=128)" if args.workload == "ds2" else f"CFM train steps/sec ({args.workload})",
+            "value": round(world * args.steps / wall, 3),
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.mode,
+            "data": "synthetic",
+            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "tokens": T, "patch_dim": P, "depth": depth, "parallelism": f"dp{world}",
+                       "params": sum(p.numel() for p in model.parameters()), "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
+            "loss": round(float(loss), 5),
+            "grad_norm": round(float(gn), 5),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
+            "mfma_util_pct": round(100.0 * achieved / peak, 2),
+        }
+        if world == 1 and not args.no_op_rates:
+            rec["gemm_ops"] = op_rates(args.mode, B * T, device)
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(shape, patch_shape, depth, B)
+            rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

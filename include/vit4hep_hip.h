@@ -105,6 +105,9 @@ int32_t v4h_op_unpatchify(const v4h_plan* plan, const float* d_tokens, float* d_
 /* learnable_pos_embedding   nn/vit.py:156-162 -> (T, D) f32 */
 int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe, void* stream);
 
+/* tuning hook (tools/gemm_bench.py only): selects the tile configuration of the plain-store and wgrad contractions */
+void v4h_debug_set_gemm_cfg(int32_t cfg, int32_t cfg_wgrad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ SIGNATURES = {
     "v4h_op_patchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "v4h_op_unpatchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "v4h_op_pos_embed": (_i32, [_vp, _vp, _vp, _vp]),
+    "v4h_debug_set_gemm_cfg": (None, [_i32, _i32]),
 }
 
 _lib = None

@@ -197,7 +197,7 @@ template <typename T> __global__ __launch_bounds__(256) void ln_modulate_fwd_ker
 // Backward of LN+modulate fused with the gate backward of the branch below.  Grid (chunks, B): a workgroup owns
 // ROWS_PER_WG consecutive tokens of ONE sample, so the per-sample sums (dshift, dscale, dgate) are reduced in
 // registers -> LDS -> one f32 atomic per feature per workgroup.
-constexpr int LNB_ROWS = 48;
+constexpr int LNB_ROWS = 16;
 template <typename T> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;

@@ -16,6 +16,8 @@
 // Tails: rows beyond I / K and 16-byte column chunks beyond the extent are zero-filled on load; stores are guarded.
 // Split-K over blockIdx.z with f32 atomics (wgrad).  Optional column sums of P over k (bias gradients) for free.
 #pragma once
+#include <type_traits>
+
 #include "v4h_common.h"
 
 enum : int {
@@ -55,79 +57,127 @@ struct GemmArgs {
   const void* P; const void* Q;
   int ldp, ldq;
   int I, J, K;
-  int klen;          // K range per blockIdx.z (multiple of BK)
+  int klen;          // K range per split (multiple of BK)
+  int nti, ntj, nz;  // tiles along i, along j, K splits (filled by the launcher; 1-D grid, XCD-aware decode in the kernel)
   float* colsum;     // optional: colsum[i] += sum_k P[i][k]   (f32 atomics; only j-tile 0 contributes)
   EpiArgs e;
 };
 
+// 8-wide vector helpers (one lane owns 8 consecutive output columns of a row)
+struct f32x8 { float v[8]; };
+V4H_DEV float& at(f32x8& x, int r) { return x.v[r]; }
+V4H_DEV f32x8 make8(f32x4 lo, f32x4 hi) {
+  f32x8 x;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { x.v[r] = lo[r]; x.v[4 + r] = hi[r]; }
+  return x;
+}
+V4H_DEV f32x8 load8(const float* p) { return make8(load4(p), load4(p + 4)); }
+V4H_DEV f32x8 load8(const bf16* p) {
+  const bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
+  f32x8 x;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) x.v[r] = (float)o[r];
+  return x;
+}
+V4H_DEV void store8(float* p, const f32x8& x) {
+  store4(p, f32x4{x.v[0], x.v[1], x.v[2], x.v[3]});
+  store4(p + 4, f32x4{x.v[4], x.v[5], x.v[6], x.v[7]});
+}
+V4H_DEV void store8(bf16* p, const f32x8& x) {
+  bf16x8 o;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = (bf16)x.v[r];
+#ifdef V4H_NT_STORES
+  __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(p));
+#else
+  *reinterpret_cast<bf16x8*>(p) = o;
+#endif
+}
+V4H_DEV f32x8 add8(f32x8 a, const f32x8& b) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) a.v[r] += b.v[r];
+  return a;
+}
+
+// Epilogue on 8 consecutive columns j..j+7 of row i (j % 8 == 0, J % 8 == 0 checked by the launcher), in two halves so
+// that the kernel can issue EVERY load of a strip before its first store: s_waitcnt vmcnt counts loads and stores in one
+// in-order queue, so a load waited for after a store would drain that store's whole round trip.
 template <int EPI, typename T, typename TO> struct Epilogue {
-  static V4H_DEV void apply(const EpiArgs& e, int i, int j, f32x4 v) {
-    if constexpr (EPI != EPI_DGELU && EPI != EPI_DSILU && EPI != EPI_ATOMIC_F32 && EPI != EPI_ACCUM_F32) {
-      if (e.bias) {
-        const f32x4 b = load4(e.bias + j);
-        v += b;
-      }
-    }
-    if constexpr (EPI == EPI_STORE) {
-      store4(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
-    } else if constexpr (EPI == EPI_STORE_F32) {
-      store4(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
-    } else if constexpr (EPI == EPI_SILU) {
-      if (e.out2) store4(reinterpret_cast<float*>(e.out2) + (size_t)i * e.ldo2 + j, v);
-      f32x4 s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[r] = silu_f(v[r]);
-      store4(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, s);
-    } else if constexpr (EPI == EPI_COND_SUM) {
-      if (e.resid) v += load4(e.resid + (size_t)i * e.ld_resid + j);
-      store4(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
-      f32x4 s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[r] = silu_f(v[r]);
-      store4(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, s);
+  struct Ops { f32x8 a, b; };
+  static constexpr bool HAS_BIAS = EPI != EPI_DGELU && EPI != EPI_DSILU && EPI != EPI_ATOMIC_F32 && EPI != EPI_ACCUM_F32;
+
+  static V4H_DEV Ops load(const EpiArgs& e, int i, int j) {
+    Ops o;
+    if constexpr (EPI == EPI_COND_SUM) {
+      if (e.resid) o.a = load8(e.resid + (size_t)i * e.ld_resid + j);
     } else if constexpr (EPI == EPI_EMBED) {
-      v += load4(e.rowvec + (size_t)(i % e.T) * e.ld_rowvec + j);
-      store4(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
+      o.a = load8(e.rowvec + (size_t)(i % e.T) * e.ld_rowvec + j);
     } else if constexpr (EPI == EPI_GATE_RESID) {
-      if (e.out2) store4(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
-      const f32x4 g = load4(e.rowvec + (size_t)(i / e.T) * e.ld_rowvec + j);
-      const f32x4 x = load4(e.resid + (size_t)i * e.ld_resid + j);
-      store4(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, x + g * v);
-    } else if constexpr (EPI == EPI_GELU) {
-      store4(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
-      f32x4 s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s[r] = gelu_tanh_f<T>(v[r]);
-      store4(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, s);
+      o.a = load8(e.rowvec + (size_t)(i / e.T) * e.ld_rowvec + j);
+      o.b = load8(e.resid + (size_t)i * e.ld_resid + j);
     } else if constexpr (EPI == EPI_DGELU) {
-      const f32x4 pre = load4(reinterpret_cast<const TO*>(e.aux) + (size_t)i * e.ld_aux + j);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= dgelu_tanh_f<T>(pre[r]);
-      store4(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+      o.a = load8(reinterpret_cast<const TO*>(e.aux) + (size_t)i * e.ld_aux + j);
     } else if constexpr (EPI == EPI_DSILU) {
-      const f32x4 pre = load4(e.auxf + (size_t)i * e.ld_auxf + j);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= dsilu_f(pre[r]);
-      store4(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
-    } else if constexpr (EPI == EPI_ATOMIC_F32) {
-      float* o = reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(o + r, v[r]);
+      o.a = load8(e.auxf + (size_t)i * e.ld_auxf + j);
     } else if constexpr (EPI == EPI_ACCUM_F32) {
-      float* o = reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j;
-      store4(o, load4(o) + v);
+      o.a = load8(reinterpret_cast<const float*>(e.out) + (size_t)i * e.ldo + j);
+    }
+    return o;
+  }
+
+  // v = accumulator (+ bias already added by the caller)
+  static V4H_DEV void finish(const EpiArgs& e, int i, int j, f32x8 v, const Ops& o) {
+    if constexpr (EPI == EPI_STORE) {
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_STORE_F32) {
+      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_SILU) {
+      if (e.out2) store8(reinterpret_cast<float*>(e.out2) + (size_t)i * e.ldo2 + j, v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] = silu_f(v.v[r]);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_COND_SUM) {
+      if (e.resid) v = add8(v, o.a);
+      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] = silu_f(v.v[r]);
+      store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
+    } else if constexpr (EPI == EPI_EMBED) {
+      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, add8(v, o.a));
+    } else if constexpr (EPI == EPI_GATE_RESID) {
+      if (e.out2) store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
+      f32x8 x = o.b;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x.v[r] += o.a.v[r] * v.v[r];
+      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, x);
+    } else if constexpr (EPI == EPI_GELU) {
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] = gelu_tanh_f<T>(v.v[r]);
+      store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
+    } else if constexpr (EPI == EPI_DGELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] *= dgelu_tanh_f<T>(o.a.v[r]);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_DSILU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] *= dsilu_f(o.a.v[r]);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_ACCUM_F32) {
+      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, add8(o.a, v));
     } else if constexpr (EPI == EPI_UNPATCH) {
       // token n = (li*a + ai)*r + ri ; feature f = (pi*p2 + pj)*p3 + pk  ->  voxel (li*p1+pi, ai*p2+pj, ri*p3+pk)
       const PatchGeom& g = e.pg;
       const int b = i / e.T, n = i % e.T;
       const int ri = n % g.r, ai = (n / g.r) % g.a, li = n / (g.r * g.a);
-      float* o = reinterpret_cast<float*>(e.out) + (size_t)b * g.L * g.A * g.R;
+      float* op = reinterpret_cast<float*>(e.out) + (size_t)b * g.L * g.A * g.R;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const int f = j + r;
         if (f < e.P) {
           const int pk = f % g.p3, pj = (f / g.p3) % g.p2, pi = f / (g.p3 * g.p2);
-          o[((size_t)(li * g.p1 + pi) * g.A + (ai * g.p2 + pj)) * g.R + (ri * g.p3 + pk)] = v[r];
+          op[((size_t)(li * g.p1 + pi) * g.A + (ai * g.p2 + pj)) * g.R + (ri * g.p3 + pk)] = v.v[r];
         }
       }
     }
@@ -166,44 +216,190 @@ template <typename T, int ROWS, int COLS, int LD> struct TileStage {
   }
 };
 
-template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int BK_, int EPI_, bool COLSUM_> struct GemmCfg {
+// ---------------------------------------------------------------------------------------------------------------------
+// Dense, XOR-swizzled LDS images filled by direct global->LDS DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction,
+// LDS destination = wave-uniform base + lane*16, no VGPR / ds_write pass).  The image is linear in DMA order; the swizzle
+// is applied to the per-lane SOURCE address and again on the fragment read (same involution), never to the destination.
+// Swizzles were chosen with tools/lds_model.py (bank model of MI355X_MICROARCH.md) to make every fragment read
+// conflict-free:  K-contiguous rows of 4 chunks: pos = kc ^ ((row & 4) >> 1);  of 8 chunks (bf16): kc ^ (row & 6);
+// of 8 chunks (f32, two chunks per lane): kc ^ (((row >> 1) & 1) | (row & 4));  K-strided bf16 (transposed read):
+// pos = chunk ^ ((k & 8) >> 2).  Out-of-range chunks are fetched from a zero page, so tails need no masking later.
+__device__ uint4 v4h_zero_page[4];
+
+template <typename T, int CPR> V4H_DEV int sw_kcontig(int row) {
+  if constexpr (CPR == 4) return (row & 4) >> 1;
+  else if constexpr (sizeof(T) == 2) return row & (CPR - 1) & 6;
+  else return ((row >> 1) & 1) | (row & 4);
+}
+template <typename T> V4H_DEV int sw_kstrided(int k) {
+  if constexpr (sizeof(T) == 2) return (k & 8) >> 2;
+  else return 0;
+}
+
+V4H_DEV void dma16(const void* g, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Both image kinds keep, per DMA instruction of this wave, the lane's source pointer for the CURRENT K-tile in registers
+// (set up once, advanced by a constant per tile), so the loop spends 2 VALU per KiB moved instead of a 64-bit
+// multiply-add chain.  Lanes whose row/column lies beyond the operand extent point at row/column 0 (their products only
+// reach output elements that are never stored); lanes beyond the K extent (last, partial tile only) read the zero page.
+
+// K-contiguous operand X[idx][k]: image rows = idx (ROWS), CPR 16-byte chunks of K per row.
+template <typename T, int ROWS, int BK, int NW> struct ImgKContig {
+  static constexpr int CH = 16 / (int)sizeof(T), CPR = BK / CH, UNITS = ROWS * CPR, NI = UNITS / 64, NPW = (NI + NW - 1) / NW;
+  static constexpr int BYTES = UNITS * 16;
+  static_assert(UNITS % 64 == 0 && (CPR == 4 || CPR == 8), "image shape");
+  const char* src[NPW];
+  int koff[NPW];  // lane's K offset (elements) inside a tile
+  V4H_DEV void init(const T* g, int ld, int idx0, int kb, int idx_end, int wave, int lane) {
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int u = (wave + n * NW) * 64 + lane, row = u / CPR, pos = u % CPR;
+      const int gi = idx0 + row;
+      koff[n] = (pos ^ sw_kcontig<T, CPR>(row)) * CH;
+      src[n] = reinterpret_cast<const char*>(g + (size_t)(gi < idx_end ? gi : 0) * ld + kb + koff[n]);
+    }
+  }
+  // stage the tile starting at k0 into img, then advance to the next tile
+  V4H_DEV void stage(char* img, int k0, int k_end, int ld, int wave) {
+    const bool full = k0 + BK <= k_end;  // scalar
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int inst = wave + n * NW;
+      if (inst < NI) {
+        const void* p = src[n];
+        if (!full && k0 + koff[n] + CH > k_end) p = v4h_zero_page;
+        dma16(p, img + inst * 1024);
+      }
+      src[n] += BK * sizeof(T);
+    }
+  }
+  // canonical fragment of rows idx0.. , K slab kk..kk+31
+  static V4H_DEV Frag<T> frag(const char* img, int idx0, int kk, int lane) {
+    const int row = idx0 + (lane & 15), g = lane >> 4;
+    Frag<T> f;
+    if constexpr (sizeof(T) == 2) {
+      const int kc = kk / 8 + g;
+      f.v = *reinterpret_cast<const bf16x8*>(img + (row * CPR + (kc ^ sw_kcontig<T, CPR>(row))) * 16);
+    } else {
+      const int kc = kk / 4 + 2 * g, s = sw_kcontig<T, CPR>(row);
+      const float4 a = *reinterpret_cast<const float4*>(img + (row * CPR + (kc ^ s)) * 16);
+      const float4 b = *reinterpret_cast<const float4*>(img + (row * CPR + ((kc + 1) ^ s)) * 16);
+      f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+      f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+    }
+    return f;
+  }
+};
+
+// K-strided operand X[k][idx]: image rows = k (BK), CPR chunks of idx per row.
+template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
+  static constexpr int CH = 16 / (int)sizeof(T), CPR = COLS / CH, UNITS = BK * CPR, NI = UNITS / 64, NPW = (NI + NW - 1) / NW;
+  static constexpr int BYTES = UNITS * 16;
+  static_assert(UNITS % 64 == 0 && CPR % 4 == 0, "image shape");
+  const char* src[NPW];
+  int krow[NPW];  // lane's row (k offset) inside a tile
+  V4H_DEV void init(const T* g, int ld, int idx0, int kb, int idx_end, int wave, int lane) {
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int u = (wave + n * NW) * 64 + lane, row = u / CPR, pos = u % CPR;
+      const int gi = idx0 + (pos ^ sw_kstrided<T>(row)) * CH;
+      krow[n] = row;
+      src[n] = reinterpret_cast<const char*>(g + (size_t)(kb + row) * ld + (gi + CH <= idx_end ? gi : 0));
+    }
+  }
+  V4H_DEV void stage(char* img, int k0, int k_end, int ld, int wave) {
+    const bool full = k0 + BK <= k_end;
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) {
+      const int inst = wave + n * NW;
+      if (inst < NI) {
+        const void* p = src[n];
+        if (!full && k0 + krow[n] >= k_end) p = v4h_zero_page;
+        dma16(p, img + inst * 1024);
+      }
+      src[n] += (size_t)BK * ld * sizeof(T);
+    }
+  }
+  static V4H_DEV Frag<T> frag(const char* img, int idx0, int kk, int lane) {
+    const int g = lane >> 4;
+    Frag<T> f;
+    if constexpr (sizeof(T) == 2) {
+      const int q = (lane >> 2) & 3, p = lane & 3;
+      const int ch = (idx0 + 4 * p) / 8, r0 = kk + 8 * g + q, r1 = r0 + 4;
+      const bf16x4 lo = lds_tr_read(reinterpret_cast<const bf16*>(img + (r0 * CPR + (ch ^ sw_kstrided<T>(r0))) * 16 + 8 * (p & 1)));
+      const bf16x4 hi = lds_tr_read(reinterpret_cast<const bf16*>(img + (r1 * CPR + (ch ^ sw_kstrided<T>(r1))) * 16 + 8 * (p & 1)));
+      f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      const int col = idx0 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = *reinterpret_cast<const float*>(img + ((kk + 8 * g + j) * CPR + col / 4) * 16 + 4 * (col & 3));
+    }
+    return f;
+  }
+};
+
+template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int BK_, int WI_, int WJ_, int EPI_, bool COLSUM_, int DBG_ = 0> struct GemmCfg {
+  static constexpr int DBG = DBG_;  // ablation builds (tools/gemm_bench.py only): 1 = staging only, 2 = compute only
   using T = T_;
   using TO = TO_;
   static constexpr bool PKS = PKS_, QKS = QKS_, COLSUM = COLSUM_;
-  static constexpr int BI = BI_, BJ = BJ_, BK = BK_, EPI = EPI_;
-  static constexpr int PAD = 16 / (int)sizeof(T);
-  // LDS images: K-contiguous operand tile[idx][BK + PAD]; K-strided operand tile[BK][idx + PAD]
-  static constexpr int P_ROWS = PKS ? BK : BI, P_COLS = PKS ? BI : BK, P_LD = P_COLS + PAD;
-  static constexpr int Q_ROWS = QKS ? BK : BJ, Q_COLS = QKS ? BJ : BK, Q_LD = Q_COLS + PAD;
-  static constexpr int P_ELEMS = P_ROWS * P_LD, Q_ELEMS = Q_ROWS * Q_LD;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)(P_ELEMS + Q_ELEMS) * sizeof(T);
-  static constexpr int WTI = BI / 2, WTJ = BJ / 2, TI = WTI / 16, TJ = WTJ / 16;
-  static_assert(BI % 32 == 0 && BJ % 32 == 0 && BK % 32 == 0, "tile shape");
+  static constexpr int BI = BI_, BJ = BJ_, BK = BK_, WI = WI_, WJ = WJ_, NW = WI_ * WJ_, NT = 64 * NW, EPI = EPI_;
+  using ImgP = typename std::conditional<PKS, ImgKStrided<T, BI, BK, NW>, ImgKContig<T, BI, BK, NW>>::type;
+  using ImgQ = typename std::conditional<QKS, ImgKStrided<T, BJ, BK, NW>, ImgKContig<T, BJ, BK, NW>>::type;
+  static constexpr int P_BYTES = ImgP::BYTES, Q_BYTES = ImgQ::BYTES;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)(P_BYTES + Q_BYTES);
+  static constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 16, TJ = WTJ / 16;
+  static_assert(BI % (16 * WI) == 0 && BJ % (16 * WJ) == 0 && BK % 32 == 0, "tile shape");
 };
 
-template <class C> __global__ __launch_bounds__(256) void v4h_gemm_kernel(const GemmArgs a) {
+template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(const GemmArgs a) {
   using T = typename C::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* const sP0 = reinterpret_cast<T*>(smem);                      // two buffers of P, then two of Q
-  T* const sQ0 = reinterpret_cast<T*>(smem) + 2 * C::P_ELEMS;
+  char* const sP0 = smem;                    // two buffers of P, then two of Q
+  char* const sQ0 = smem + 2 * C::P_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wi = wave >> 1, wj = wave & 1;
-  const int i0 = blockIdx.x * C::BI, j0 = blockIdx.y * C::BJ;
-  const int kb = blockIdx.z * a.klen;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave / C::WJ, wj = wave % C::WJ;
+  // Block -> (i-tile, j-tile, k-split).  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so
+  // bid % 8 labels the XCD.  Speed only - any placement gives the same result.
+  //  * no split: XCD x owns the i-tiles (tokens) == x (mod 8) and sweeps all j-tiles of one i-tile back to back: the
+  //    activation tile is fetched into that L2 once and the whole weight matrix stays L2-resident.
+  //  * split-K (wgrad): split z lives on XCD z % 8 and all output tiles of a split run together, so the token rows of
+  //    the split are fetched once per XCD and shared by every output tile.
+  int ti, tj, tz;
+  {
+    const int bid = blockIdx.x;
+    if (a.nz == 1) {
+      const int xcd = bid & 7, slot = bid >> 3;
+      tj = slot % a.ntj;
+      ti = (slot / a.ntj) * 8 + xcd;
+      tz = 0;
+      if (ti >= a.nti) return;  // whole workgroup leaves together (before any barrier)
+    } else {
+      tz = bid % a.nz;
+      const int tile = bid / a.nz;
+      ti = tile % a.nti;
+      tj = tile / a.nti;
+    }
+  }
+  const int i0 = ti * C::BI, j0 = tj * C::BJ;
+  const int kb = tz * a.klen;
   const int ke = min(a.K, kb + a.klen);
   const int nt = (ke - kb + C::BK - 1) / C::BK;
   const T* gP = reinterpret_cast<const T*>(a.P);
   const T* gQ = reinterpret_cast<const T*>(a.Q);
 
-  TileStage<T, C::P_ROWS, C::P_COLS, C::P_LD> stP;
-  TileStage<T, C::Q_ROWS, C::Q_COLS, C::Q_LD> stQ;
-  auto gload = [&](int t) {
+  typename C::ImgP stP;
+  typename C::ImgQ stQ;
+  stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
+  stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
+  auto stage = [&](int t, int buf) {  // tiles must be staged in order t = 0, 1, 2, ... (the stagers advance their pointers)
     const int k0 = kb + t * C::BK;
-    if constexpr (C::PKS) stP.load(gP, a.ldp, k0, i0, ke, a.I, tid);
-    else stP.load(gP, a.ldp, i0, k0, a.I, ke, tid);
-    if constexpr (C::QKS) stQ.load(gQ, a.ldq, k0, j0, ke, a.J, tid);
-    else stQ.load(gQ, a.ldq, j0, k0, a.J, ke, tid);
+    stP.stage(sP0 + buf * C::P_BYTES, k0, ke, a.ldp, wave);
+    stQ.stage(sQ0 + buf * C::Q_BYTES, k0, ke, a.ldq, wave);
   };
 
   f32x4 acc[C::TI][C::TJ];
@@ -215,33 +411,21 @@ template <class C> __global__ __launch_bounds__(256) void v4h_gemm_kernel(const 
 #pragma unroll
   for (int x = 0; x < C::TI; ++x) cs[x] = 0.f;
 
-  if (nt > 0) {
-    gload(0);
-    stP.store(sP0, tid);
-    stQ.store(sQ0, tid);
-  }
-  __syncthreads();
+  if (nt > 0) stage(0, 0);
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nt) gload(t + 1);
-    const T* tp = sP0 + cur * C::P_ELEMS;
-    const T* tq = sQ0 + cur * C::Q_ELEMS;
+    if (t + 1 < nt && (C::DBG != 2)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
+    const char* tp = sP0 + cur * C::P_BYTES;
+    const char* tq = sQ0 + cur * C::Q_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < C::BK; kk += 32) {
+    for (int kk = 0; kk < (C::DBG == 1 ? 0 : C::BK); kk += 32) {
       Frag<T> pf[C::TI], qf[C::TJ];
 #pragma unroll
-      for (int x = 0; x < C::TI; ++x) {
-        const int idx = wi * C::WTI + x * 16;
-        if constexpr (C::PKS) pf[x] = frag_kstrided<T>(tp, C::P_LD, kk, idx, lane);
-        else pf[x] = frag_kcontig(tp, C::P_LD, idx, kk, lane);
-      }
+      for (int x = 0; x < C::TI; ++x) pf[x] = C::ImgP::frag(tp, wi * C::WTI + x * 16, kk, lane);
 #pragma unroll
-      for (int y = 0; y < C::TJ; ++y) {
-        const int idx = wj * C::WTJ + y * 16;
-        if constexpr (C::QKS) qf[y] = frag_kstrided<T>(tq, C::Q_LD, kk, idx, lane);
-        else qf[y] = frag_kcontig(tq, C::Q_LD, idx, kk, lane);
-      }
+      for (int y = 0; y < C::TJ; ++y) qf[y] = C::ImgQ::frag(tq, wj * C::WTJ + y * 16, kk, lane);
       if constexpr (C::COLSUM) {
 #pragma unroll
         for (int x = 0; x < C::TI; ++x)
@@ -253,25 +437,84 @@ template <class C> __global__ __launch_bounds__(256) void v4h_gemm_kernel(const 
 #pragma unroll
         for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);
     }
-    if (t + 1 < nt) {
-      stP.store(sP0 + (cur ^ 1) * C::P_ELEMS, tid);
-      stQ.store(sQ0 + (cur ^ 1) * C::Q_ELEMS, tid);
-    }
-    __syncthreads();
+    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading the current one
   }
 
   const int c = lane & 15, g = lane >> 4;
+  if constexpr (C::EPI == EPI_ATOMIC_F32) {
+    // Split-K accumulation with f32 atomics.  Float atomics run at the memory side at full rate only when one
+    // wave-instruction covers >= 128 contiguous bytes per row (MI355X_MICROARCH.md, Global float atomics); the MFMA
+    // accumulator layout (16 rows x isolated dwords per instruction) is the ~17x slower shape.  So each wave passes its
+    // tile through a private LDS strip, 16 rows at a time, and adds 64 consecutive floats of a row per instruction.
+    constexpr int SLD = C::WTJ + 4;
+    static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES, "atomic staging strip must fit the operand LDS");
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
+    float* outp = reinterpret_cast<float*>(a.e.out);
 #pragma unroll
-  for (int x = 0; x < C::TI; ++x) {
-    const int i = i0 + wi * C::WTI + x * 16 + c;
+    for (int x = 0; x < C::TI; ++x) {
 #pragma unroll
-    for (int y = 0; y < C::TJ; ++y) {
-      const int j = j0 + wj * C::WTJ + y * 16 + 4 * g;
-      if (i < a.I && j < a.J) Epilogue<C::EPI, T, typename C::TO>::apply(a.e, i, j, acc[x][y]);
+      for (int y = 0; y < C::TJ; ++y) *reinterpret_cast<f32x4*>(strip + c * SLD + y * 16 + 4 * g) = acc[x][y];
+      __syncthreads();
+      const int ib = i0 + wi * C::WTI + x * 16, jb = j0 + wj * C::WTJ;
+      for (int id = lane; id < 16 * C::WTJ; id += 64) {
+        const int row = id / C::WTJ, col = id % C::WTJ;
+        if (ib + row < a.I && jb + col < a.J) atomicAdd(outp + (size_t)(ib + row) * a.e.ldo + jb + col, strip[row * SLD + col]);
+      }
+      __syncthreads();
+    }
+  } else if constexpr (C::DBG != 3) {
+    // Every other epilogue: the MFMA accumulator layout (a lane holds 4 columns of ONE row, 16 rows per instruction) makes
+    // 8-byte stores into 16 different cache lines.  Instead each wave passes its tile through a private LDS strip, 16 rows
+    // at a time, and each lane then owns 8 CONSECUTIVE columns of a row: 16/32-byte accesses, WTJ*sizeof contiguous per row,
+    // for the output and for every epilogue operand (bias, residual, gate, pre-activation).
+    constexpr int SLD = C::WTJ + 4, CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
+    using Epi = Epilogue<C::EPI, T, typename C::TO>;
+    static_assert(C::WTJ % 8 == 0, "wave tile width must be a multiple of 8");
+    static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES, "epilogue staging strip must fit the operand LDS");
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
+    const int jb = j0 + wj * C::WTJ;
+    int rrow[NIT], rcol[NIT];
+    bool cok[NIT];
+    f32x8 bias8[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {  // a lane's chunk columns (and their bias) are the same for every strip
+      const int id = lane + it * 64;
+      rrow[it] = id / CPRW;
+      rcol[it] = (id % CPRW) * 8;
+      cok[it] = id < NCH && jb + rcol[it] < a.J;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) bias8[it].v[r] = 0.f;
+      if constexpr (Epi::HAS_BIAS) {
+        if (a.e.bias != nullptr && cok[it]) bias8[it] = load8(a.e.bias + jb + rcol[it]);
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < C::TI; ++x) {
+#pragma unroll
+      for (int y = 0; y < C::TJ; ++y) *reinterpret_cast<f32x4*>(strip + c * SLD + y * 16 + 4 * g) = acc[x][y];
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: LDS strip visible to the wave; global stores stay in flight
+      __builtin_amdgcn_wave_barrier();
+      const int ib = i0 + wi * C::WTI + x * 16;
+      f32x8 v[NIT];
+      typename Epi::Ops ops[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {  // phase 1: LDS reads + every global load of the strip
+        if (cok[it] && ib + rrow[it] < a.I) {
+          v[it] = add8(make8(*reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it]),
+                             *reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it] + 4)), bias8[it]);
+          ops[it] = Epi::load(a.e, ib + rrow[it], jb + rcol[it]);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {  // phase 2: math + stores
+        if (cok[it] && ib + rrow[it] < a.I) Epi::finish(a.e, ib + rrow[it], jb + rcol[it], v[it], ops[it]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if constexpr (C::COLSUM) {
-    if (a.colsum != nullptr && blockIdx.y == 0 && wj == 0) {
+    if (a.colsum != nullptr && tj == 0 && wj == 0) {
 #pragma unroll
       for (int x = 0; x < C::TI; ++x) {
         float s = cs[x];
@@ -287,7 +530,7 @@ template <class C> __global__ __launch_bounds__(256) void v4h_gemm_kernel(const 
 template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t stream, const char* name) {
   V4H_CHECK_ARG(a.I > 0 && a.J > 0 && a.K > 0, "%s: empty problem I=%d J=%d K=%d", name, a.I, a.J, a.K);
   constexpr int CH = 16 / (int)sizeof(typename C::T);
-  V4H_CHECK_ARG(a.J % 4 == 0, "%s: J=%d must be a multiple of 4", name, a.J);
+  V4H_CHECK_ARG(a.J % 8 == 0 || C::EPI == EPI_ATOMIC_F32, "%s: J=%d must be a multiple of 8", name, a.J);
   V4H_CHECK_ARG(a.ldp % CH == 0 && a.ldq % CH == 0, "%s: operand row strides (%d,%d) must be whole 16-byte chunks", name, a.ldp, a.ldq);
   V4H_CHECK_ARG(C::PKS ? (a.I % CH == 0) : (a.K % CH == 0), "%s: P extent not a whole number of 16-byte chunks", name);
   V4H_CHECK_ARG(C::QKS ? (a.J % CH == 0) : (a.K % CH == 0), "%s: Q extent not a whole number of 16-byte chunks", name);
@@ -297,8 +540,12 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + C::BK - 1) / C::BK * C::BK;
   a.klen = klen;
-  const int nz = (a.K + klen - 1) / klen;
-  dim3 grid((a.I + C::BI - 1) / C::BI, (a.J + C::BJ - 1) / C::BJ, nz);
+  a.nz = (a.K + klen - 1) / klen;
+  a.nti = (a.I + C::BI - 1) / C::BI;
+  a.ntj = (a.J + C::BJ - 1) / C::BJ;
+  const long nblocks = a.nz == 1 ? (long)((a.nti + 7) / 8) * 8 * a.ntj : (long)a.nti * a.ntj * a.nz;
+  V4H_CHECK_ARG(nblocks < (1L << 31), "%s: grid too large", name);
+  dim3 grid((unsigned)nblocks);
   static bool attr_set = false;
   if (!attr_set && C::LDS_BYTES > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -309,7 +556,7 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(v4h_gemm_kernel<C>, grid, dim3(256), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL(v4h_gemm_kernel<C>, grid, dim3(C::NT), C::LDS_BYTES, stream, a);
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;
 }

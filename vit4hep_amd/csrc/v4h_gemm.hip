@@ -4,14 +4,58 @@
 namespace v4h {
 namespace {
 
+// K-step: 64 for bf16 (128-byte rows = whole cache lines per DMA row, half the barriers), 32 for f32 (also 128-byte rows)
+template <typename T> constexpr int bk_of() { return sizeof(T) == 2 ? 64 : 32; }
+
 template <typename T, typename TO, bool PKS, bool QKS, int BI, int BJ, int EPI, bool CS = false>
 int run(const GemmArgs& a, int splitk, hipStream_t s, const char* name) {
-  return v4h_gemm_launch<GemmCfg<T, TO, PKS, QKS, BI, BJ, 32, EPI, CS>>(a, splitk, s, name);
+  return v4h_gemm_launch<GemmCfg<T, TO, PKS, QKS, BI, BJ, bk_of<T>(), 2, 2, EPI, CS>>(a, splitk, s, name);
+}
+
+// ---- tile-shape tuning hook (tools/gemm_bench.py): selects the configuration used for EPI_STORE fwd/dgrad and wgrad ----
+int g_cfg = 0, g_cfg_wgrad = 0;
+template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a, hipStream_t s, const char* name) {
+  if constexpr (sizeof(T) == 2) {
+    switch (g_cfg) {
+      case 2: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 3: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 32, 4, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 4: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 96, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 5: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 96, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 6: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 8: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 1>>(a, 1, s, name);
+      case 9: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 2>>(a, 1, s, name);
+      case 13: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 14: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
+      case 12: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
+      case 10: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false, 1>>(a, 1, s, name);
+      case 11: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false, 2>>(a, 1, s, name);
+      default: break;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (g_cfg == 7) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false>>(a, 1, s, name);
+  }
+  return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, bk_of<T>(), 2, 2, EPI_STORE, false>>(a, 1, s, name);
+}
+template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    switch (g_cfg_wgrad) {
+      case 1: return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 160, 64, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+      case 2: return v4h_gemm_launch<GemmCfg<T, T, true, true, 320, 160, 32, 4, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+      case 3: return v4h_gemm_launch<GemmCfg<T, T, true, true, 320, 160, 64, 4, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+      default: break;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (g_cfg_wgrad == 7) return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 160, 32, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+    return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 64, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+  }
+  return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 32, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
 }
 
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
-    case EPI_STORE: return run<T, T, false, false, 128, 160, EPI_STORE>(a, 1, s, "gemm_fwd/store");
+    case EPI_STORE: return run_store_cfg<T, false>(a, s, "gemm_fwd/store");
     case EPI_STORE_F32: return run<T, T, false, false, 128, 160, EPI_STORE_F32>(a, 1, s, "gemm_fwd/store_f32");
     case EPI_SILU: return run<T, T, false, false, 128, 160, EPI_SILU>(a, 1, s, "gemm_fwd/silu");
     case EPI_COND_SUM: return run<T, T, false, false, 128, 160, EPI_COND_SUM>(a, 1, s, "gemm_fwd/cond_sum");
@@ -24,13 +68,14 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   return V4H_ERR_UNSUPPORTED;
 }
 
-template <typename T> int dgrad_t(int epi, const GemmArgs& a, hipStream_t s) {
+template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStream_t s) {
   switch (epi) {
-    case EPI_STORE: return run<T, T, false, true, 128, 160, EPI_STORE>(a, 1, s, "gemm_dgrad/store");
+    case EPI_STORE: return run_store_cfg<T, true>(a, s, "gemm_dgrad/store");
     case EPI_DGELU: return run<T, T, false, true, 128, 160, EPI_DGELU>(a, 1, s, "gemm_dgrad/dgelu");
     case EPI_DSILU: return run<T, T, false, true, 128, 160, EPI_DSILU>(a, 1, s, "gemm_dgrad/dsilu");
     case EPI_ACCUM_F32: return run<T, T, false, true, 128, 160, EPI_ACCUM_F32>(a, 1, s, "gemm_dgrad/accum");
     case EPI_STORE_F32: return run<T, T, false, true, 128, 160, EPI_STORE_F32>(a, 1, s, "gemm_dgrad/store_f32");
+    case EPI_ATOMIC_F32: return run<T, T, false, true, 128, 160, EPI_ATOMIC_F32>(a, splitk, s, "gemm_dgrad/atomic");
   }
   v4h_set_error("gemm_dgrad: epilogue %d not built", epi);
   return V4H_ERR_UNSUPPORTED;
@@ -39,10 +84,11 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int gemm_fwd(Mode m, int epi, const GemmArgs& a, hipStream_t s) { return m == MODE_BF16 ? fwd_t<bf16>(epi, a, s) : fwd_t<float>(epi, a, s); }
-int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s) { return m == MODE_BF16 ? dgrad_t<bf16>(epi, a, s) : dgrad_t<float>(epi, a, s); }
+int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk) { return m == MODE_BF16 ? dgrad_t<bf16>(epi, a, splitk, s) : dgrad_t<float>(epi, a, splitk, s); }
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s) {
-  if (m == MODE_BF16) return run<bf16, bf16, true, true, 160, 160, EPI_ATOMIC_F32, true>(a, splitk, s, "gemm_wgrad");
-  return run<float, float, true, true, 160, 160, EPI_ATOMIC_F32, true>(a, splitk, s, "gemm_wgrad");
+  return m == MODE_BF16 ? run_wgrad_cfg<bf16>(a, splitk, s) : run_wgrad_cfg<float>(a, splitk, s);
 }
+
+void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg; g_cfg_wgrad = cfg_wgrad; }
 
 }  // namespace v4h

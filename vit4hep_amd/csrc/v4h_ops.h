@@ -10,8 +10,10 @@ inline size_t esize(Mode m) { return m == MODE_BF16 ? 2 : 4; }
 
 // ---- contractions (v4h_gemm.hip) ----
 int gemm_fwd(Mode m, int epi, const GemmArgs& a, hipStream_t s);              // P contig, Q contig
-int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s);            // P contig, Q K-strided
+int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk = 1);  // P contig, Q K-strided (split-K only with EPI_ATOMIC_F32)
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s);         // both K-strided, f32 atomics (+ colsum)
+
+void debug_set_gemm_cfg(int cfg, int cfg_wgrad);  // tile-shape tuning hook
 
 // ---- attention (v4h_attention.hip) ----
 int attention_fwd(Mode m, const void* qkv, void* o, float* lse, int B, int T, int H, int DH, hipStream_t s);

@@ -235,12 +235,14 @@ static GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int
   return a;
 }
 
+// K splits of a wgrad: a multiple of 8 (one or more per XCD) giving about one workgroup per CU; every split costs one
+// f32-atomic pass over the output (~1.3 TB/s chip-wide), so no more than that.
 static int wgrad_splitk(int I, int J, int K) {
-  const int tiles = ((I + 159) / 160) * ((J + 159) / 160);
-  int sk = (768 + tiles - 1) / tiles;
-  const int maxk = K / 256 > 1 ? K / 256 : 1;
+  const int tiles = ((I + 159) / 160) * ((J + 95) / 96);
+  int sk = tiles >= 40 ? 8 : 16;
+  if (tiles < 8) sk = 32;
+  const int maxk = K / 128;  // at least 4 K-steps per split
   if (sk > maxk) sk = maxk;
-  if (sk > 64) sk = 64;
   return sk < 1 ? 1 : sk;
 }
 // dW[I][J] += dY^T X  (+ db[I] += column sums of dY)
@@ -358,9 +360,9 @@ static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int 
   CastPadItem it{dmod, w.dmod_t, B, J, B, J, 0};
   RUN(cast_pad_many(c.p.mode, &it, 1, c.s));
   RUN(wgrad(c, w.dmod_t, J, J, w.silu_c, D, D, B, (float*)grads[widx], D, (float*)grads[bidx]));
-  GemmArgs a = gargs(w.dmod_t, J, c.W(widx), D, B, D, J);
+  GemmArgs a = gargs(w.dmod_t, J, c.W(widx), D, B, D, J);  // M = B rows only: spread the long K over the chip instead
   a.e.out = w.dsilu; a.e.ldo = D;
-  return gemm_dgrad(c.p.mode, EPI_ACCUM_F32, a, c.s);
+  return gemm_dgrad(c.p.mode, EPI_ATOMIC_F32, a, c.s, J / 96);
 }
 
 extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
@@ -493,6 +495,8 @@ extern "C" int32_t v4h_rk4_combine(float* y, const float* k1, const float* k2, c
   V4H_CHECK_ARG(y && k1 && k2 && k3 && k4 && n > 0, "rk4_combine: bad argument");
   return rk4_combine(y, k1, k2, k3, k4, h, n, (hipStream_t)s);
 }
+
+extern "C" void v4h_debug_set_gemm_cfg(int32_t cfg, int32_t cfg_wgrad) { debug_set_gemm_cfg(cfg, cfg_wgrad); }
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t pks, const void* Q, int32_t ldq, int32_t qks, const float* bias, void* out,
