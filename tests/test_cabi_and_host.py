@@ -1,0 +1,158 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/vit4hep_hip.h declares; plan / error behaviour;
+host mirror classes keep the reference's constructor, state-dict keys and initialisation; no compute without a GPU."""
+
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_cfm_oracle as O
+from vit4hep_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(REPO, "include", "vit4hep_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(v4h_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    assert _lib.load().v4h_abi_version() == 1
+
+
+def test_plan_inventory_matches_reference_state_dict():
+    for cfg in (O.ds2(6), O.ds3(6), O.ds2(2)):
+        plan = _lib.Plan(cfg.shape, cfg.patch_shape, cfg.condition_dim, cfg.hidden_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden)
+        assert plan.shapes == [tuple(s) for s in O.param_shapes(cfg).values()]
+        assert plan.num_stages == cfg.depth + 2
+        assert plan.workspace_bytes(128, True) > plan.workspace_bytes(128, False) > 0
+        assert plan.workspace_bytes(256, True) > plan.workspace_bytes(128, True)
+
+
+def test_plan_rejects_what_the_reference_asserts():
+    with pytest.raises(RuntimeError, match=r"Input size \(45\) should be divisible by patch size \(4\) in axis 0"):
+        _lib.Plan((45, 16, 9), (4, 16, 1), 46, 480, 2, 6, 1920)  # calochallenge_cfm/model.py:33-36
+    with pytest.raises(RuntimeError, match="divisible by num_heads"):
+        _lib.Plan((45, 16, 9), (3, 16, 1), 46, 480, 2, 7, 1920)  # nn/vit.py:411
+    with pytest.raises(RuntimeError, match="head_dim"):
+        _lib.Plan((45, 16, 9), (3, 16, 1), 46, 384, 2, 6, 1536)
+
+
+def _model(depth=2, **extra):
+    from vit4hep_amd import CaloChallengeCFM, ViT
+
+    param = {"dim": 3, "condition_dim": 46, "hidden_dim": 480, "out_channels": 1, "depth": depth, "num_heads": 6, "mlp_ratio": 4, "attn_drop": 0.0,
+             "proj_drop": 0.0, "pos_embedding_coords": "cylindrical", "temperature": 10000, "learn_pos_embed": True, "causal_attn": False,
+             "checkpoint_grads": False, "num_patches": [[15, 1, 9]], "patch_dim": 48, "use_torch_sdpa": False, "use_rotary_emb": False}
+    param.update(extra)
+    net = ViT(param)
+    return CaloChallengeCFM(net, [3, 16, 1], in_channels=1, time_distribution="uniform", trajectory="linear",
+                            odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=[45, 16, 9])
+
+
+def test_state_dict_keys_and_init_match_reference():
+    torch.manual_seed(0)
+    m = _model(2)
+    cfg = O.ds2(2)
+    want = ["net." + k for k in O.param_shapes(cfg)]
+    got = [k for k, _ in m.named_parameters()]
+    assert got == want
+    assert [k for k, _ in m.named_buffers()] == ["net.pos_z", "net.pos_y", "net.pos_x"]
+    assert sum(p.numel() for p in m.parameters()) == 9424928
+    sd = m.state_dict()
+    pz, py, px = O.meshgrid_buffers(cfg)
+    assert torch.equal(sd["net.pos_z"], pz) and torch.equal(sd["net.pos_y"], py) and torch.equal(sd["net.pos_x"], px)
+    for k, v in sd.items():  # nn/vit.py:164-183
+        if k.endswith("bias") or "adaLN_modulation" in k or k.startswith("net.final_layer.linear"):
+            assert float(v.abs().max()) == 0.0, k
+        elif k.endswith("weight"):
+            bound = math.sqrt(6.0 / (v.shape[0] + v.shape[1]))
+            assert 0.5 * bound < float(v.abs().max()) <= bound * (1 + 1e-6), k
+    # round trip with "module." prefixes stripped, as experiments/misc.py:65-71 does after DDP
+    m2 = _model(2)
+    ddp_sd = {k.replace("net.", "net.module.", 1): v for k, v in sd.items()}  # keys as saved from DDP(model.net)
+    m2.load_state_dict({k.replace("module.", ""): v for k, v in ddp_sd.items()})
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_reference_attribute_surface():
+    m = _model(2)
+    net = m.net
+    for name in ("x_embedder", "c_embedder", "t_embedder", "blocks", "final_layer", "pos_embed_freqs", "learn_pos_embed", "num_patches", "pos_z", "pos_y", "pos_x",
+                 "create_meshgrid", "learnable_pos_embedding", "initialize_weights"):
+        assert hasattr(net, name), name  # reached into by experiment_finetuning.py:80-196
+    assert m.num_patches == [15, 1, 9] and m.patch_shape == [3, 16, 1] and m.in_channels == 1
+    assert type(net).__name__ == "ViT"
+
+
+def test_unsupported_options_fail_loudly():
+    from vit4hep_amd import ViT
+
+    base = {"hidden_dim": 480, "depth": 1, "num_heads": 6, "mlp_ratio": 4, "patch_dim": 48, "num_patches": [[15, 1, 9]]}
+    for bad in ({"learn_pos_embed": False}, {"causal_attn": True}, {"attn_drop": 0.1}, {"num_patches": [[5, 1, 9], [10, 1, 9]]}):
+        with pytest.raises(NotImplementedError):
+            ViT({**base, **bad})
+    with pytest.raises(ValueError):
+        ViT({**base, "amd_mode": "fp8"})
+    from vit4hep_amd import CFM
+
+    with pytest.raises(ValueError):
+        CFM(None, trajectory="sine", shape=[1])  # models/base_model.py:186-190
+    with pytest.raises(ValueError):
+        CFM(None, time_distribution="beta", shape=[1])
+
+
+def test_no_cpu_fallback():
+    m = _model(1)
+    m.device, m.dtype = torch.device("cpu"), torch.float32
+    x, c, _ = O.synthetic_batch(O.ds2(1), 2, 0)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m.forward(x, torch.rand(2, 1), c)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m._batch_loss([x, c])
+    from vit4hep_amd.trainer import CFMTrainer
+
+    with pytest.raises(RuntimeError, match="MI355X"):
+        CFMTrainer(m)
+
+
+def test_solver_grid_and_lr_schedule_match_oracle():
+    from vit4hep_amd.models.base_model import fixed_grid
+
+    for step in (0.05, 0.25, 0.5, 0.3):
+        assert np.array_equal(fixed_grid(0.0, 1.0, step), O.fixed_grid(0.0, 1.0, step).numpy())
+    st = O.AdamWState(iterations=50)
+    lr = lambda k: 1e-4 * 0.5 * (1.0 + math.cos(math.pi * k / 50))
+    assert all(abs(st.lr_at(k) - lr(k)) < 1e-18 for k in range(60))
+
+
+def test_dropin_aliases_reference_module_paths():
+    import importlib
+    import sys
+
+    from vit4hep_amd import dropin
+
+    saved = {k: sys.modules.get(k) for k in dropin.ALIASES}
+    try:
+        dropin.install()
+        assert importlib.import_module("nn.vit").ViT is importlib.import_module("vit4hep_amd.nn.vit").ViT
+        mod = importlib.import_module("experiments.calochallenge.calochallenge_cfm.model")
+        assert mod.CaloChallengeCFM.__module__.startswith("vit4hep_amd")
+        assert importlib.import_module("models.base_model").CFM.__module__.startswith("vit4hep_amd")
+    finally:
+        dropin.uninstall()
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v

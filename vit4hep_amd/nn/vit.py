@@ -136,7 +136,7 @@ class ViT(nn.Module):
         """Buffers pos_z/pos_y/pos_x on the patch grid (reference nn/vit.py:137-154), single segment."""
         l, a, r = self.num_patches[0]
         z, y, x = torch.meshgrid(torch.arange(l) / l, torch.arange(a) / a, torch.arange(r) / r, indexing="ij")
-        return z.flatten(), y.flatten(), x.flatten()
+        return z.flatten().clone(), y.flatten().clone(), x.flatten().clone()  # real storage (meshgrid returns expanded views)
 
     def learnable_pos_embedding(self):
         """(T, D) table from pos_embed_freqs, computed by the HIP kernel (reference nn/vit.py:156-162)."""
