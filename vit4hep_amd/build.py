@@ -20,7 +20,7 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvit4hep_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"] + os.environ.get("V4H_EXTRA_FLAGS", "").split()
 
 
 def _sources():

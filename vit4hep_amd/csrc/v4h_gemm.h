@@ -58,6 +58,7 @@ struct GemmArgs {
   int ldp, ldq;
   int I, J, K;
   int klen;          // K range per split (multiple of BK)
+  int stagger_sleeps;  // tuning: s_sleep(127) count (8128 cycles each) for the second half of a persistent grid
   int nti, ntj, nz;  // tiles along i, along j, K splits (filled by the launcher; 1-D grid, XCD-aware decode in the kernel)
   float* colsum;     // optional: colsum[i] += sum_k P[i][k]   (f32 atomics; only j-tile 0 contributes)
   EpiArgs e;
@@ -354,53 +355,71 @@ template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int
   static_assert(BI % (16 * WI) == 0 && BJ % (16 * WJ) == 0 && BK % 32 == 0, "tile shape");
 };
 
-template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(const GemmArgs a) {
+// 4-wave workgroups must fit two per CU (2 waves / SIMD, i.e. <= 256 VGPR+AGPR): several epilogue variants sit just above that
+// and would silently halve their occupancy.
+template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) void v4h_gemm_kernel(const GemmArgs a) {
   using T = typename C::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const sP0 = smem;                    // two buffers of P, then two of Q
-  char* const sQ0 = smem + 2 * C::P_BYTES;
+  constexpr int BUF_BYTES = C::P_BYTES + C::Q_BYTES;  // LDS: [P0 | Q0 | P1 | Q1]; epilogue strips re-use buffer 1
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / C::WJ, wj = wave % C::WJ;
-  // Block -> (i-tile, j-tile, k-split).  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so
-  // bid % 8 labels the XCD.  Speed only - any placement gives the same result.
+  const T* gP = reinterpret_cast<const T*>(a.P);
+  const T* gQ = reinterpret_cast<const T*>(a.Q);
+
+  // Virtual block id -> (i-tile, j-tile, k-split).  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2
+  // each), so id % 8 labels the XCD (the grid is a multiple of 8).  Speed only - any placement gives the same result.
   //  * no split: XCD x owns the i-tiles (tokens) == x (mod 8) and sweeps all j-tiles of one i-tile back to back: the
-  //    activation tile is fetched into that L2 once and the whole weight matrix stays L2-resident.
+  //    activation tile is fetched into that L2 once and the whole weight matrix stays L2-resident.  The workgroup is
+  //    PERSISTENT: it walks virtual ids id, id + grid, ... and never waits for its output stores - a workgroup's LDS and
+  //    registers are only handed to a successor once its stores have drained, which otherwise costs one store round trip
+  //    per tile (measured: as long as the whole K = 480 main loop).
   //  * split-K (wgrad): split z lives on XCD z % 8 and all output tiles of a split run together, so the token rows of
-  //    the split are fetched once per XCD and shared by every output tile.
-  int ti, tj, tz;
-  {
-    const int bid = blockIdx.x;
+  //    the split are fetched once per XCD and shared by every output tile; one tile per workgroup.
+  const int nvirt = a.nz == 1 ? ((a.nti + 7) / 8) * 8 * a.ntj : a.nti * a.ntj * a.nz;
+  auto decode = [&](int v, int& ti, int& tj, int& tz) -> bool {
+    if (v >= nvirt) return false;
     if (a.nz == 1) {
-      const int xcd = bid & 7, slot = bid >> 3;
+      const int xcd = v & 7, slot = v >> 3;
       tj = slot % a.ntj;
       ti = (slot / a.ntj) * 8 + xcd;
       tz = 0;
-      if (ti >= a.nti) return;  // whole workgroup leaves together (before any barrier)
-    } else {
-      tz = bid % a.nz;
-      const int tile = bid / a.nz;
-      ti = tile % a.nti;
-      tj = tile / a.nti;
+      return ti < a.nti;
     }
+    tz = v % a.nz;
+    const int tile = v / a.nz;
+    ti = tile % a.nti;
+    tj = tile / a.nti;
+    return true;
+  };
+
+  // Stagger: the workgroups that share a CU run the same program with the same tile time, i.e. in lockstep (both in
+  // their main loop, then both in their store phase).  Holding back the second half of the persistent grid by roughly half
+  // a tile lets one workgroup's epilogue overlap its partner's MFMAs.
+  if (a.stagger_sleeps > 0 && a.nz == 1 && blockIdx.x >= gridDim.x / 2) {
+    for (int n = 0; n < a.stagger_sleeps; ++n) __builtin_amdgcn_s_sleep(127);
   }
+
+  typename C::ImgP stP;
+  typename C::ImgQ stQ;
+  int ti, tj, tz;
+  bool staged = false;  // tile 0 of the current virtual id already in flight / landed in buffer 0
+  for (int v = blockIdx.x; decode(v, ti, tj, tz); v += gridDim.x) {
   const int i0 = ti * C::BI, j0 = tj * C::BJ;
   const int kb = tz * a.klen;
   const int ke = min(a.K, kb + a.klen);
   const int nt = (ke - kb + C::BK - 1) / C::BK;
-  const T* gP = reinterpret_cast<const T*>(a.P);
-  const T* gQ = reinterpret_cast<const T*>(a.Q);
-
-  typename C::ImgP stP;
-  typename C::ImgQ stQ;
-  stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
-  stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
   auto stage = [&](int t, int buf) {  // tiles must be staged in order t = 0, 1, 2, ... (the stagers advance their pointers)
     const int k0 = kb + t * C::BK;
-    stP.stage(sP0 + buf * C::P_BYTES, k0, ke, a.ldp, wave);
-    stQ.stage(sQ0 + buf * C::Q_BYTES, k0, ke, a.ldq, wave);
+    stP.stage(smem + buf * BUF_BYTES, k0, ke, a.ldp, wave);
+    stQ.stage(smem + buf * BUF_BYTES + C::P_BYTES, k0, ke, a.ldq, wave);
   };
+  if (!staged) {
+    stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
+    stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
+    if (nt > 0) stage(0, 0);
+  }
 
   f32x4 acc[C::TI][C::TJ];
 #pragma unroll
@@ -411,14 +430,13 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
 #pragma unroll
   for (int x = 0; x < C::TI; ++x) cs[x] = 0.f;
 
-  if (nt > 0) stage(0, 0);
-  __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave
+  __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
 
   for (int t = 0; t < nt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nt && (C::DBG != 2)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
-    const char* tp = sP0 + cur * C::P_BYTES;
-    const char* tq = sQ0 + cur * C::Q_BYTES;
+    const char* tp = smem + cur * BUF_BYTES;
+    const char* tq = tp + C::P_BYTES;
 #pragma unroll
     for (int kk = 0; kk < (C::DBG == 1 ? 0 : C::BK); kk += 32) {
       Frag<T> pf[C::TI], qf[C::TJ];
@@ -435,9 +453,24 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
 #pragma unroll
       for (int x = 0; x < C::TI; ++x)
 #pragma unroll
-        for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);
+        for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);  // (s_setprio around the cluster measured 40 % slower here)
     }
     __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading the current one
+  }
+
+  // Prefetch the first K-slab of this workgroup's NEXT output tile into buffer 0 before the epilogue (strips use buffer 1).
+  {
+    int nti_, ntj_, ntz_;
+    staged = false;
+    if (C::EPI != EPI_ATOMIC_F32 && a.nz == 1 && decode(v + gridDim.x, nti_, ntj_, ntz_)) {
+      stP.init(gP, a.ldp, nti_ * C::BI, 0, a.I, wave, lane);
+      stQ.init(gQ, a.ldq, ntj_ * C::BJ, 0, a.J, wave, lane);
+      if (a.K > 0) {
+        stP.stage(smem, 0, a.K, a.ldp, wave);
+        stQ.stage(smem + C::P_BYTES, 0, a.K, a.ldq, wave);
+      }
+      staged = true;
+    }
   }
 
   const int c = lane & 15, g = lane >> 4;
@@ -448,7 +481,7 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
     // tile through a private LDS strip, 16 rows at a time, and adds 64 consecutive floats of a row per instruction.
     constexpr int SLD = C::WTJ + 4;
     static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES, "atomic staging strip must fit the operand LDS");
-    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
+    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);  // no prefetch in flight on this path
     float* outp = reinterpret_cast<float*>(a.e.out);
 #pragma unroll
     for (int x = 0; x < C::TI; ++x) {
@@ -462,6 +495,15 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
       }
       __syncthreads();
     }
+  } else if constexpr (C::DBG == 4) {
+    // ablation (tools/gemm_bench.py): keep every MFMA live but write 16 bytes per lane per tile instead of the whole tile
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < C::TI; ++x)
+#pragma unroll
+      for (int y = 0; y < C::TJ; ++y) sum += acc[x][y];
+    const int i = i0 + wi * C::WTI + c, j = j0 + wj * C::WTJ + 4 * g;
+    if (i < a.I && j < a.J) store4(reinterpret_cast<typename C::TO*>(a.e.out) + (size_t)i * a.e.ldo + j, sum);
   } else if constexpr (C::DBG != 3) {
     // Every other epilogue: the MFMA accumulator layout (a lane holds 4 columns of ONE row, 16 rows per instruction) makes
     // 8-byte stores into 16 different cache lines.  Instead each wave passes its tile through a private LDS strip, 16 rows
@@ -470,8 +512,8 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
     constexpr int SLD = C::WTJ + 4, CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
     using Epi = Epilogue<C::EPI, T, typename C::TO>;
     static_assert(C::WTJ % 8 == 0, "wave tile width must be a multiple of 8");
-    static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES, "epilogue staging strip must fit the operand LDS");
-    float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);
+    static_assert(C::NW * 16 * SLD * sizeof(float) <= BUF_BYTES, "epilogue staging strip must fit one operand buffer");
+    float* strip = reinterpret_cast<float*>(smem + BUF_BYTES) + wave * (16 * SLD);
     const int jb = j0 + wj * C::WTJ;
     int rrow[NIT], rcol[NIT];
     bool cok[NIT];
@@ -525,6 +567,7 @@ template <class C> __global__ __launch_bounds__(C::NT) void v4h_gemm_kernel(cons
       }
     }
   }
+  }  // persistent tile loop
 }
 
 template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t stream, const char* name) {
@@ -543,8 +586,13 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
   a.nz = (a.K + klen - 1) / klen;
   a.nti = (a.I + C::BI - 1) / C::BI;
   a.ntj = (a.J + C::BJ - 1) / C::BJ;
-  const long nblocks = a.nz == 1 ? (long)((a.nti + 7) / 8) * 8 * a.ntj : (long)a.nti * a.ntj * a.nz;
+  long nblocks = a.nz == 1 ? (long)((a.nti + 7) / 8) * 8 * a.ntj : (long)a.nti * a.ntj * a.nz;
   V4H_CHECK_ARG(nblocks < (1L << 31), "%s: grid too large", name);
+  if (a.nz == 1) {  // persistent workgroups: as many as are co-resident (256 CUs x workgroups per CU by LDS), a multiple of 8
+    const long per_cu = (160 * 1024) / (long)C::LDS_BYTES > 0 ? (160 * 1024) / (long)C::LDS_BYTES : 1;
+    const long resident = 256 * (per_cu > 2 ? 2 : per_cu);
+    if (nblocks > resident) nblocks = resident;
+  }
   dim3 grid((unsigned)nblocks);
   static bool attr_set = false;
   if (!attr_set && C::LDS_BYTES > 48 * 1024) {

@@ -13,12 +13,13 @@ int run(const GemmArgs& a, int splitk, hipStream_t s, const char* name) {
 }
 
 // ---- tile-shape tuning hook (tools/gemm_bench.py): selects the configuration used for EPI_STORE fwd/dgrad and wgrad ----
-int g_cfg = 0, g_cfg_wgrad = 0;
-template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a, hipStream_t s, const char* name) {
+int g_cfg = 0, g_cfg_wgrad = 0, g_stagger = 0;
+template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_t s, const char* name) {
+  GemmArgs a = a0;
+  a.stagger_sleeps = g_stagger;
   if constexpr (sizeof(T) == 2) {
     switch (g_cfg) {
       case 2: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
-      case 3: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 32, 4, 2, EPI_STORE, false>>(a, 1, s, name);
       case 4: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 96, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
       case 5: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 96, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
       case 6: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
@@ -26,6 +27,7 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a, hipStream_t
       case 9: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 2>>(a, 1, s, name);
       case 13: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
       case 14: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
+      case 15: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 4>>(a, 1, s, name);
       case 12: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
       case 10: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false, 1>>(a, 1, s, name);
       case 11: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false, 2>>(a, 1, s, name);
@@ -33,7 +35,6 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a, hipStream_t
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (g_cfg == 7) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false>>(a, 1, s, name);
   }
   return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, bk_of<T>(), 2, 2, EPI_STORE, false>>(a, 1, s, name);
 }
@@ -89,6 +90,6 @@ int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s) {
   return m == MODE_BF16 ? run_wgrad_cfg<bf16>(a, splitk, s) : run_wgrad_cfg<float>(a, splitk, s);
 }
 
-void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg; g_cfg_wgrad = cfg_wgrad; }
+void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad; }
 
 }  // namespace v4h
