@@ -81,8 +81,19 @@ template <typename T, int DH> V4H_DEV void accumulate_wz(f32x4* out, const f32x4
   }
 }
 
+// one 32-row step of the above: W given as the two accumulator tiles 2*ks, 2*ks+1
+template <typename T, int DH> V4H_DEV void accumulate_wz_step(f32x4* out, f32x4 w0, f32x4 w1, const T* ztile, int ks, int lane) {
+  using C = AttnCfg<T, DH>;
+  const Frag<T> wf = frag_from_acc(w0, w1, T());
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt) {
+    const Frag<T> zf = frag_kstrided2(ztile, C::LD, 32 * ks, 32 * ks + 16, dt * 16, lane);
+    out[dt] = mma(zf, wf, out[dt]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- forward
-template <typename T, int DH> __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o, float* __restrict__ lse,
                                                                                       int Tn, int H, float scale) {
   using C = AttnCfg<T, DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -93,10 +104,10 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_fwd_ke
   const int D = H * DH, ld = 3 * D;
   const T* base = qkv + (size_t)b * Tn * ld + h * DH;
   const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
-  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+  const int nrounds = (ntiles + NW * gridDim.y - 1) / (NW * gridDim.y);
 
   for (int rd = 0; rd < nrounds; ++rd) {
-    const int qt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const int qt = (rd * gridDim.y + blockIdx.y) * NW + wave;
     const bool active = qt < ntiles;  // wave-uniform
     Frag<T> xq[C::NKF];
     load_row_frags<T, DH>(xq, base, ld, qt * 16, active ? Tn : 0, lane);
@@ -108,7 +119,7 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_fwd_ke
     for (int ch = 0; ch < nchunks; ++ch) {
       if (!(nchunks == 1 && rd > 0)) {
         __syncthreads();
-        TileStage<T, KC, DH, C::LD> st;
+        TileStage<T, KC, DH, C::LD, 64 * NW> st;
         st.load(base + D, ld, ch * KC, 0, Tn, DH, tid);
         st.store(sK, tid);
         st.load(base + 2 * D, ld, ch * KC, 0, Tn, DH, tid);
@@ -178,7 +189,7 @@ template <typename T> __global__ void attn_delta_kernel(const T* __restrict__ o,
 }
 
 // dQ: lane side = queries, streamed = keys (K and V chunks in LDS)
-template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
                                                                                          const float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H, float scale) {
   using C = AttnCfg<T, DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -190,10 +201,10 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dq
   const T* base = qkv + (size_t)b * Tn * ld + h * DH;
   const T* dobase = dout + (size_t)b * Tn * D + h * DH;
   const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
-  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+  const int nrounds = (ntiles + NW * gridDim.y - 1) / (NW * gridDim.y);
 
   for (int rd = 0; rd < nrounds; ++rd) {
-    const int qt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const int qt = (rd * gridDim.y + blockIdx.y) * NW + wave;
     const bool active = qt < ntiles;
     const int q = qt * 16 + c;
     Frag<T> xq[C::NKF], xdo[C::NKF];
@@ -211,27 +222,31 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dq
     for (int ch = 0; ch < nchunks; ++ch) {
       if (!(nchunks == 1 && rd > 0)) {
         __syncthreads();
-        TileStage<T, KC, DH, C::LD> st;
+        TileStage<T, KC, DH, C::LD, 64 * NW> st;
         st.load(base + D, ld, ch * KC, 0, Tn, DH, tid);
         st.store(sK, tid);
         st.load(base + 2 * D, ld, ch * KC, 0, Tn, DH, tid);
         st.store(sV, tid);
         __syncthreads();
       }
-      if (active) {
-        f32x4 ds[C::NJT];
+      if (active) {  // two key tiles at a time: scores -> dS -> straight into dQ (keeps the live set small)
 #pragma unroll
-        for (int jt = 0; jt < C::NJT; ++jt) {
-          const f32x4 s = score_tile<T, DH>(sK, jt, xq, lane);
-          const f32x4 dp = score_tile<T, DH>(sV, jt, xdo, lane);
+        for (int ks = 0; ks < C::NJT / 2; ++ks) {
+          f32x4 ds2[2];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = ch * KC + jt * 16 + 4 * g + r;
-            const float p = (key < Tn && q < Tn) ? __expf(s[r] * scale - lse_q) : 0.f;
-            ds[jt][r] = p * (dp[r] - delta_q) * scale;
+          for (int hh = 0; hh < 2; ++hh) {
+            const int jt = 2 * ks + hh;
+            const f32x4 s = score_tile<T, DH>(sK, jt, xq, lane);
+            const f32x4 dp = score_tile<T, DH>(sV, jt, xdo, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = ch * KC + jt * 16 + 4 * g + r;
+              const float p = (key < Tn && q < Tn) ? __expf(s[r] * scale - lse_q) : 0.f;
+              ds2[hh][r] = p * (dp[r] - delta_q) * scale;
+            }
           }
+          accumulate_wz_step<T, DH>(dq, ds2[0], ds2[1], sK, ks, lane);
         }
-        accumulate_wz<T, DH>(dq, ds, sK, lane);
       }
     }
     if (active && q < Tn) {
@@ -243,7 +258,7 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dq
 }
 
 // dK, dV: lane side = keys, streamed = queries (Q and dO chunks + their lse / delta in LDS)
-template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
                                                                                           const float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H, float scale) {
   using C = AttnCfg<T, DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,10 +274,10 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dk
   const float* lse_bh = lse + ((size_t)b * H + h) * Tn;
   const float* delta_bh = delta + ((size_t)b * H + h) * Tn;
   const int ntiles = (Tn + 15) / 16, nchunks = (Tn + KC - 1) / KC;
-  const int nrounds = (ntiles + 4 * gridDim.y - 1) / (4 * gridDim.y);
+  const int nrounds = (ntiles + NW * gridDim.y - 1) / (NW * gridDim.y);
 
   for (int rd = 0; rd < nrounds; ++rd) {
-    const int kt = (rd * gridDim.y + blockIdx.y) * 4 + wave;
+    const int kt = (rd * gridDim.y + blockIdx.y) * NW + wave;
     const bool active = kt < ntiles;
     const int key = kt * 16 + c;
     Frag<T> xk[C::NKF], xv[C::NKF];
@@ -277,7 +292,7 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dk
     for (int ch = 0; ch < nchunks; ++ch) {
       if (!(nchunks == 1 && rd > 0)) {
         __syncthreads();
-        TileStage<T, KC, DH, C::LD> st;
+        TileStage<T, KC, DH, C::LD, 64 * NW> st;
         st.load(base, ld, ch * KC, 0, Tn, DH, tid);
         st.store(sQ, tid);
         st.load(dobase, D, ch * KC, 0, Tn, DH, tid);
@@ -289,24 +304,28 @@ template <typename T, int DH> __global__ __launch_bounds__(256) void attn_bwd_dk
         }
         __syncthreads();
       }
-      if (active) {
-        f32x4 pt[C::NJT], dst[C::NJT];
+      if (active) {  // two query tiles at a time: P^T, dS^T -> straight into dV, dK
 #pragma unroll
-        for (int jt = 0; jt < C::NJT; ++jt) {
-          const f32x4 s = score_tile<T, DH>(sQ, jt, xk, lane);
-          const f32x4 dp = score_tile<T, DH>(sDO, jt, xv, lane);
-          const f32x4 ls = *reinterpret_cast<const f32x4*>(sLse + jt * 16 + 4 * g);
-          const f32x4 de = *reinterpret_cast<const f32x4*>(sDelta + jt * 16 + 4 * g);
+        for (int ks = 0; ks < C::NJT / 2; ++ks) {
+          f32x4 pt2[2], dst2[2];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qq = ch * KC + jt * 16 + 4 * g + r;
-            const float p = (qq < Tn && key < Tn) ? __expf(s[r] * scale - ls[r]) : 0.f;
-            pt[jt][r] = p;
-            dst[jt][r] = p * (dp[r] - de[r]) * scale;
+          for (int hh = 0; hh < 2; ++hh) {
+            const int jt = 2 * ks + hh;
+            const f32x4 s = score_tile<T, DH>(sQ, jt, xk, lane);
+            const f32x4 dp = score_tile<T, DH>(sDO, jt, xv, lane);
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(sLse + jt * 16 + 4 * g);
+            const f32x4 de = *reinterpret_cast<const f32x4*>(sDelta + jt * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = ch * KC + jt * 16 + 4 * g + r;
+              const float p = (qq < Tn && key < Tn) ? __expf(s[r] * scale - ls[r]) : 0.f;
+              pt2[hh][r] = p;
+              dst2[hh][r] = p * (dp[r] - de[r]) * scale;
+            }
           }
+          accumulate_wz_step<T, DH>(dv, pt2[0], pt2[1], sDO, ks, lane);
+          accumulate_wz_step<T, DH>(dk, dst2[0], dst2[1], sQ, ks, lane);
         }
-        accumulate_wz<T, DH>(dv, pt, sDO, lane);
-        accumulate_wz<T, DH>(dk, dst, sQ, lane);
       }
     }
     if (active && key < Tn) {
@@ -331,40 +350,51 @@ template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
   return V4H_OK;
 }
 
-template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
-  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80 = 480/6, every shipped shape-CFM config)", DH);
+// One workgroup per (batch, head): K/V (or Q/dO) are loaded once and every 16-row tile of the lane-side sequence gets a
+// wave.  9 waves when the tile count is a multiple of 9 (ds2: T = 135 -> 9 tiles, no idle wave), else 8 (ds3: 29 tiles).
+template <typename T, int NW> int attn_fwd_launch(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
   using C = AttnCfg<T, 80>;
-  const size_t lds = 2 * (size_t)C::TILE_ELEMS * sizeof(T);
-  int rc = set_lds(attn_fwd_kernel<T, 80>, lds, "attn_fwd");
+  const size_t lds = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
+  int rc = set_lds(attn_fwd_kernel<T, 80, NW>, lds, "attn_fwd");
   if (rc) return rc;
-  const int ntiles = (Tn + 15) / 16;
-  dim3 grid(B * H, (ntiles + 3) / 4);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, 80>), grid, dim3(256), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
+  hipLaunchKernelGGL((attn_fwd_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
   V4H_CHECK_LAUNCH("attn_fwd");
   return V4H_OK;
 }
+template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
+  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80 = 480/6, every shipped shape-CFM config)", DH);
+  const int ntiles = (Tn + 15) / 16;
+  if (sizeof(T) == 4 || ntiles <= 4) return attn_fwd_launch<T, 4>(qkv, o, lse, B, Tn, H, DH, s);  // f32: 8 VGPRs per fragment -> 256-register budget
+  if (ntiles % 9 == 0) return attn_fwd_launch<T, 9>(qkv, o, lse, B, Tn, H, DH, s);
+  return attn_fwd_launch<T, 8>(qkv, o, lse, B, Tn, H, DH, s);
+}
 
+template <typename T, int NW> int attn_bwd_launch(const void* qkv, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH,
+                                                 hipStream_t s) {
+  using C = AttnCfg<T, 80>;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const size_t lds_q = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
+  int rc = set_lds(attn_bwd_dq_kernel<T, 80, NW>, lds_q, "attn_bwd_dq");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_q, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  V4H_CHECK_LAUNCH("attn_bwd_dq");
+  const size_t lds_kv = lds_q + 2 * KC * sizeof(float);
+  rc = set_lds(attn_bwd_dkv_kernel<T, 80, NW>, lds_kv, "attn_bwd_dkv");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_kv, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  V4H_CHECK_LAUNCH("attn_bwd_dkv");
+  return V4H_OK;
+}
 template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH,
                                      hipStream_t s) {
   V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80)", DH);
-  using C = AttnCfg<T, 80>;
   const int BT = B * Tn;
   hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((BT * H + 255) / 256), dim3(256), 0, s, (const T*)o, (const T*)dout, delta, BT, Tn, H, DH);
   V4H_CHECK_LAUNCH("attn_delta");
-  const float scale = 1.0f / sqrtf((float)DH);
   const int ntiles = (Tn + 15) / 16;
-  dim3 grid(B * H, (ntiles + 3) / 4);
-  const size_t lds_q = 2 * (size_t)C::TILE_ELEMS * sizeof(T);
-  int rc = set_lds(attn_bwd_dq_kernel<T, 80>, lds_q, "attn_bwd_dq");
-  if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80>), grid, dim3(256), lds_q, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
-  V4H_CHECK_LAUNCH("attn_bwd_dq");
-  const size_t lds_kv = lds_q + 2 * KC * sizeof(float);
-  rc = set_lds(attn_bwd_dkv_kernel<T, 80>, lds_kv, "attn_bwd_dkv");
-  if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 80>), grid, dim3(256), lds_kv, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
-  V4H_CHECK_LAUNCH("attn_bwd_dkv");
-  return V4H_OK;
+  if (sizeof(T) == 4 || ntiles <= 4) return attn_bwd_launch<T, 4>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+  if (ntiles % 9 == 0) return attn_bwd_launch<T, 9>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+  return attn_bwd_launch<T, 8>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
 }
 
 }  // namespace

@@ -159,6 +159,14 @@ template <typename T> V4H_DEV float dgelu_tanh_f(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
 }
 
+// gelu_tanh(x) and its derivative from ONE tanh (forward epilogue stores both; the backward is then a plain multiply)
+template <typename T> V4H_DEV void gelu_and_grad(float x, float& y, float& dy) {
+  const float x2 = x * x;
+  const float t = tanh_m<T>(0.7978845608028654f * (x + 0.044715f * x * x2));
+  y = 0.5f * x * (1.0f + t);
+  dy = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+}
+
 V4H_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

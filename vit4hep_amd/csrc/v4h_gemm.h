@@ -27,8 +27,8 @@ enum : int {
   EPI_COND_SUM,       // s = acc + bias + (resid? resid[i][j] : 0) ; out(f32) = s ; out2(TO) = silu(s)
   EPI_EMBED,          // out(f32) = acc + bias + rowvec[(i % T)][j]                (x_embedder + pos-emb)
   EPI_GATE_RESID,     // y = acc + bias ; out2(TO) = y ; out(f32) = resid + gate[b(i)][j] * y
-  EPI_GELU,           // pre = acc + bias ; out(TO) = pre ; out2(TO) = gelu_tanh(pre)
-  EPI_DGELU,          // out(TO) = acc * gelu_tanh'(aux(TO)[i][j])
+  EPI_GELU,           // pre = acc + bias ; out(TO) = gelu_tanh'(pre) ; out2(TO) = gelu_tanh(pre)   (one tanh serves both)
+  EPI_DGELU,          // out(TO) = acc * aux(TO)[i][j]        (aux = gelu_tanh'(pre) saved by the forward)
   EPI_DSILU,          // out(TO) = acc * silu'(auxf(f32)[i][j])
   EPI_ATOMIC_F32,     // atomicAdd(out(f32)[i][j], acc)
   EPI_ACCUM_F32,      // out(f32)[i][j] += acc
@@ -153,13 +153,14 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       for (int r = 0; r < 8; ++r) x.v[r] += o.a.v[r] * v.v[r];
       store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, x);
     } else if constexpr (EPI == EPI_GELU) {
-      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+      f32x8 d;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v.v[r] = gelu_tanh_f<T>(v.v[r]);
+      for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);
       store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
     } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v.v[r] *= dgelu_tanh_f<T>(o.a.v[r]);
+      for (int r = 0; r < 8; ++r) v.v[r] *= o.a.v[r];
       store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
     } else if constexpr (EPI == EPI_DSILU) {
 #pragma unroll
@@ -186,18 +187,18 @@ template <int EPI, typename T, typename TO> struct Epilogue {
 };
 
 // 2-D tile copy global -> registers -> LDS in 16-byte chunks, zero-filled outside [0,rows_end) x [0,cols_end).
-template <typename T, int ROWS, int COLS, int LD> struct TileStage {
+template <typename T, int ROWS, int COLS, int LD, int NT = 256> struct TileStage {
   static constexpr int CH = 16 / (int)sizeof(T);
   static constexpr int CPR = COLS / CH;
   static constexpr int TOTAL = ROWS * CPR;
-  static constexpr int N = (TOTAL + 255) / 256;
+  static constexpr int N = (TOTAL + NT - 1) / NT;
   static_assert(COLS % CH == 0, "tile columns must be whole 16-byte chunks");
   uint4 r[N];
 
   V4H_DEV void load(const T* g, int ld, int row0, int col0, int rows_end, int cols_end, int tid) {
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      const int c = tid + n * 256;
+      const int c = tid + n * NT;
       const int tr = c / CPR, tc = (c % CPR) * CH;
       const int gr = row0 + tr, gc = col0 + tc;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -208,7 +209,7 @@ template <typename T, int ROWS, int COLS, int LD> struct TileStage {
   V4H_DEV void store(T* s, int tid) const {
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      const int c = tid + n * 256;
+      const int c = tid + n * NT;
       if (c < TOTAL) {
         const int tr = c / CPR, tc = (c % CPR) * CH;
         *reinterpret_cast<uint4*>(s + tr * LD + tc) = r[n];

@@ -101,7 +101,7 @@ extern "C" int32_t v4h_vit_num_backward_stages(const v4h_plan* p) { return p ? p
 // ------------------------------------------------------------------------------------------------ workspace layout
 struct BlockWS {
   float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
-  char *u1, *qkv, *o, *y1, *u2, *hpre, *h, *y2;
+  char *u1, *qkv, *o, *y1, *u2, *hgrad, *h, *y2;
 };
 struct WS {
   std::vector<char*> wop;       // operand-typed (cast / padded) weights, null where the f32 parameter itself is used
@@ -166,7 +166,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     b.lse = (float*)take((size_t)B * p.H * p.T * 4);
     b.x_mid = (float*)take(BT * D * 4);
     b.u1 = take(BT * D * es); b.qkv = take(BT * 3 * D * es); b.o = take(BT * D * es); b.y1 = take(BT * D * es);
-    b.u2 = take(BT * D * es); b.hpre = take(BT * M * es); b.h = take(BT * M * es); b.y2 = take(BT * D * es);
+    b.u2 = take(BT * D * es); b.hgrad = take(BT * M * es); b.h = take(BT * M * es); b.y2 = take(BT * D * es);
   }
   w.blk.resize(p.depth);
   for (int i = 0; i < p.depth; ++i) w.blk[i] = bs[training ? i : 0];
@@ -336,7 +336,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
     RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, 6 * D, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
     a = gargs(b.u2, D, c.W(p->blk(i, B_FC1W)), D, BT, M, D);
-    a.e.out = b.hpre; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M; a.e.bias = c.pf(p->blk(i, B_FC1B));
+    a.e.out = b.hgrad; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M;  /* hgrad = gelu_tanh'(fc1 output), h = gelu_tanh(fc1 output) */ a.e.bias = c.pf(p->blk(i, B_FC1B));
     RUN(gemm_fwd(m, EPI_GELU, a, c.s));
     a = gargs(b.h, M, c.W(p->blk(i, B_FC2W)), M, BT, D, M);
     a.e.out = w.X[i + 1]; a.e.ldo = D; a.e.out2 = training ? b.y2 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_FC2B));
@@ -409,7 +409,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
       RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)]));
       GemmArgs a = gargs(w.dy, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
-      a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hpre; a.e.ld_aux = M;
+      a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
       RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
       RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)]));
       a = gargs(w.dhpre, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
