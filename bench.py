@@ -142,8 +142,11 @@ def main():
     device = f"cuda:{local_rank}"
     import torch.distributed as dist
 
-    if world > 1:
+    if world > 1 or os.environ.get("V4H_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", init_method="env://", device_id=torch.device(device))
 
@@ -151,7 +154,7 @@ def main():
 
     shape, patch_shape, depth, B, desc = WORKLOADS[args.workload]
     model = build_model(shape, patch_shape, depth, args.mode, device)
-    if world > 1:  # same initial weights everywhere, like DDP's constructor broadcast (base_experiment.py:163)
+    if dist.is_initialized():  # same initial weights everywhere, like DDP's constructor broadcast (base_experiment.py:163)
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
@@ -160,7 +163,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,7 +181,7 @@ def main():
     dev_ms = e0.elapsed_time(e1)
     CFMTrainer.check_finite(gn)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
 
@@ -217,7 +220,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(shape, patch_shape, depth, B)
             rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,8 +15,19 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_enabled():
+    """True when gradient collectives must run: more than one rank, or V4H_FORCE_COLLECTIVES=1 with an initialised
+    process group (exercises the RCCL / stream plumbing on a single GPU; a 1-rank all-reduce is the identity)."""
+    if world() > 1:
+        return True
+    return os.environ.get("V4H_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
 
 
 class BucketReducer:
@@ -29,7 +40,7 @@ class BucketReducer:
 
     def reduce_slice(self, lo: int, hi: int):
         """Call right after the kernels producing flat[lo:hi] were enqueued on the current stream."""
-        if world() == 1 or hi <= lo:
+        if not collectives_enabled() or hi <= lo:
             return
         view = self.flat[lo:hi]
         if self.cuda:

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import _lib
 from .autograd import run_backward, run_forward
-from .parallel import BucketReducer, world
+from .parallel import BucketReducer, collectives_enabled, world
 
 
 def _aligned(n, a=64):
@@ -136,7 +136,7 @@ class CFMTrainer:
             "v4h_adamw_step",
         )
         out_loss = loss.clone()
-        if world() > 1:
+        if collectives_enabled():
             dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
             out_loss /= world()
         return out_loss, self.gnorm_sq.sqrt()
