@@ -172,25 +172,10 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 }
 
 // ------------------------------------------------------------------------------------------------- backward
-// delta[b,h,t] = sum_d dO[t][d] * O[t][d]
-template <typename T> __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ delta, int BT, int Tn, int H, int DH) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (token, head)
-  if (idx >= BT * H) return;
-  const int tok = idx / H, h = idx % H;
-  const T* po = o + (size_t)tok * H * DH + h * DH;
-  const T* pd = dout + (size_t)tok * H * DH + h * DH;
-  float s = 0.f;
-  for (int d = 0; d < DH; d += 4) {
-    const f32x4 a = load4(po + d), bb = load4(pd + d);
-    s += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
-  }
-  const int b = tok / Tn, t = tok % Tn;
-  delta[((size_t)b * H + h) * Tn + t] = s;
-}
-
 // dQ: lane side = queries, streamed = keys (K and V chunks in LDS)
-template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
-                                                                                         const float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H, float scale) {
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o, const T* __restrict__ dout,
+                                                                                         const float* __restrict__ lse, float* __restrict__ delta, T* __restrict__ dqkv, int Tn, int H,
+                                                                                         float scale) {
   using C = AttnCfg<T, DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* sK = reinterpret_cast<T*>(smem);
@@ -210,10 +195,21 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
     Frag<T> xq[C::NKF], xdo[C::NKF];
     load_row_frags<T, DH>(xq, base, ld, qt * 16, active ? Tn : 0, lane);
     load_row_frags<T, DH>(xdo, dobase, D, qt * 16, active ? Tn : 0, lane);
+    // delta[q] = sum_d dO[q][d] * O[q][d]: the lane already holds its slice of the dO row; same slice of O, 2 shuffles
     float lse_q = 0.f, delta_q = 0.f;
+    {
+      Frag<T> xo[C::NKF];
+      load_row_frags<T, DH>(xo, o + (size_t)b * Tn * D + h * DH, D, qt * 16, active ? Tn : 0, lane);
+#pragma unroll
+      for (int s2 = 0; s2 < C::NKF; ++s2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) delta_q += to_f32(xo[s2].v[jj]) * to_f32(xdo[s2].v[jj]);
+      delta_q += __shfl_xor(delta_q, 16, 64);
+      delta_q += __shfl_xor(delta_q, 32, 64);
+    }
     if (active && q < Tn) {
       lse_q = lse[((size_t)b * H + h) * Tn + q];
-      delta_q = delta[((size_t)b * H + h) * Tn + q];
+      if (g == 0) delta[((size_t)b * H + h) * Tn + q] = delta_q;  // for the dK/dV pass
     }
     f32x4 dq[C::NDT];
 #pragma unroll
@@ -369,14 +365,14 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
   return attn_fwd_launch<T, 8>(qkv, o, lse, B, Tn, H, DH, s);
 }
 
-template <typename T, int NW> int attn_bwd_launch(const void* qkv, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH,
-                                                 hipStream_t s) {
+template <typename T, int NW> int attn_bwd_launch(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H,
+                                                 int DH, hipStream_t s) {
   using C = AttnCfg<T, 80>;
   const float scale = 1.0f / sqrtf((float)DH);
   const size_t lds_q = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
   int rc = set_lds(attn_bwd_dq_kernel<T, 80, NW>, lds_q, "attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_q, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_q, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
   V4H_CHECK_LAUNCH("attn_bwd_dq");
   const size_t lds_kv = lds_q + 2 * KC * sizeof(float);
   rc = set_lds(attn_bwd_dkv_kernel<T, 80, NW>, lds_kv, "attn_bwd_dkv");
@@ -388,13 +384,10 @@ template <typename T, int NW> int attn_bwd_launch(const void* qkv, const void* d
 template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int B, int Tn, int H, int DH,
                                      hipStream_t s) {
   V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80)", DH);
-  const int BT = B * Tn;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((BT * H + 255) / 256), dim3(256), 0, s, (const T*)o, (const T*)dout, delta, BT, Tn, H, DH);
-  V4H_CHECK_LAUNCH("attn_delta");
   const int ntiles = (Tn + 15) / 16;
-  if (sizeof(T) == 4 || ntiles <= 4) return attn_bwd_launch<T, 4>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
-  if (ntiles % 9 == 0) return attn_bwd_launch<T, 9>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
-  return attn_bwd_launch<T, 8>(qkv, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+  if (sizeof(T) == 4 || ntiles <= 4) return attn_bwd_launch<T, 4>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+  if (ntiles % 9 == 0) return attn_bwd_launch<T, 9>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
+  return attn_bwd_launch<T, 8>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
 }
 
 }  // namespace

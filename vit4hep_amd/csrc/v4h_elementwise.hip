@@ -143,8 +143,8 @@ template <typename T> __global__ void timestep_embed_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------ LayerNorm + modulate
 // nn.LayerNorm(D, elementwise_affine=False, eps=1e-6) then modulate (nn/vit.py:309,457-458).  One wave per token row;
 // lane owns float4 groups lane*4 + 256*n.  Two-pass statistics in registers.
-constexpr int LN_MAXV = 4;  // D <= 1024
-template <typename T> __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+// NV = float4 groups per lane (D <= 256 * NV); the kernels are instantiated for NV = 2 (D = 480) and 4
+template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
                                                                                      const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
                                                                                      float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D) {
   const int lane = threadIdx.x & 63;
@@ -198,7 +198,7 @@ template <typename T> __global__ __launch_bounds__(256) void ln_modulate_fwd_ker
 // ROWS_PER_WG consecutive tokens of ONE sample, so the per-sample sums (dshift, dscale, dgate) are reduced in
 // registers -> LDS -> one f32 atomic per feature per workgroup.
 constexpr int LNB_ROWS = 16;
-template <typename T> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
+template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * LNB_ROWS;
@@ -442,18 +442,28 @@ int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t 
 }
 int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
                     hipStream_t s) {
-  V4H_CHECK_ARG(D % 4 == 0 && D <= 256 * LN_MAXV, "ln_modulate: hidden_dim %d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
+  V4H_CHECK_ARG(D % 4 == 0 && D <= 1024, "ln_modulate: hidden_dim %d unsupported (multiple of 4, <= 1024)", D);
   const dim3 grid((BT + 3) / 4);
-  if (m == MODE_BF16) hipLaunchKernelGGL(ln_modulate_fwd_kernel<bf16>, grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
-  else hipLaunchKernelGGL(ln_modulate_fwd_kernel<float>, grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+  if (D <= 512) {
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
+    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+  } else {
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 4>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
+    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 4>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+  }
   V4H_CHECK_LAUNCH("ln_modulate_fwd");
   return V4H_OK;
 }
 int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
-  V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 256 * LN_MAXV, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
+  V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 1024, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
   const dim3 grid((a.T + LNB_ROWS - 1) / LNB_ROWS, a.B);
-  if (m == MODE_BF16) hipLaunchKernelGGL(ln_modulate_bwd_kernel<bf16>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(ln_modulate_bwd_kernel<float>, grid, dim3(256), 0, s, a);
+  if (a.D <= 512) {
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_bwd_kernel<bf16, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_modulate_bwd_kernel<float, 2>), grid, dim3(256), 0, s, a);
+  } else {
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_bwd_kernel<bf16, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((ln_modulate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, a);
+  }
   V4H_CHECK_LAUNCH("ln_modulate_bwd");
   return V4H_OK;
 }
