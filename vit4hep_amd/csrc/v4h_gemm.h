@@ -252,6 +252,7 @@ template <typename T, int ROWS, int BK, int NW> struct ImgKContig {
   static constexpr int CH = 16 / (int)sizeof(T), CPR = BK / CH, UNITS = ROWS * CPR, NI = UNITS / 64, NPW = (NI + NW - 1) / NW;
   static constexpr int BYTES = UNITS * 16;
   static_assert(UNITS % 64 == 0 && (CPR == 4 || CPR == 8), "image shape");
+  static V4H_DEV int count(int wave) { return (NI - wave + NW - 1) / NW; }  // DMA instructions this wave issues per tile
   const char* src[NPW];
   int koff[NPW];  // lane's K offset (elements) inside a tile
   V4H_DEV void init(const T* g, int ld, int idx0, int kb, int idx_end, int wave, int lane) {
@@ -300,6 +301,7 @@ template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
   static constexpr int CH = 16 / (int)sizeof(T), CPR = COLS / CH, UNITS = BK * CPR, NI = UNITS / 64, NPW = (NI + NW - 1) / NW;
   static constexpr int BYTES = UNITS * 16;
   static_assert(UNITS % 64 == 0 && CPR % 4 == 0, "image shape");
+  static V4H_DEV int count(int wave) { return (NI - wave + NW - 1) / NW; }
   const char* src[NPW];
   int krow[NPW];  // lane's row (k offset) inside a tile
   V4H_DEV void init(const T* g, int ld, int idx0, int kb, int idx_end, int wave, int lane) {
@@ -342,7 +344,8 @@ template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
   }
 };
 
-template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int BK_, int WI_, int WJ_, int EPI_, bool COLSUM_, int DBG_ = 0> struct GemmCfg {
+template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int BK_, int WI_, int WJ_, int EPI_, bool COLSUM_, int DBG_ = 0, int NSTAGE_ = 2> struct GemmCfg {
+  static constexpr int NSTAGE = NSTAGE_;  // LDS ring depth: 2 = one tile ahead (vmcnt(0) per step), 4 = three tiles ahead, counted vmcnt
   static constexpr int DBG = DBG_;  // ablation builds (tools/gemm_bench.py only): 1 = staging only, 2 = compute only
   using T = T_;
   using TO = TO_;
@@ -351,10 +354,23 @@ template <typename T_, typename TO_, bool PKS_, bool QKS_, int BI_, int BJ_, int
   using ImgP = typename std::conditional<PKS, ImgKStrided<T, BI, BK, NW>, ImgKContig<T, BI, BK, NW>>::type;
   using ImgQ = typename std::conditional<QKS, ImgKStrided<T, BJ, BK, NW>, ImgKContig<T, BJ, BK, NW>>::type;
   static constexpr int P_BYTES = ImgP::BYTES, Q_BYTES = ImgQ::BYTES;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)(P_BYTES + Q_BYTES);
+  static constexpr size_t LDS_BYTES = NSTAGE * (size_t)(P_BYTES + Q_BYTES);
+  static_assert(NSTAGE == 2 || NSTAGE == 4, "ring depth");
   static constexpr int WTI = BI / WI, WTJ = BJ / WJ, TI = WTI / 16, TJ = WTJ / 16;
   static_assert(BI % (16 * WI) == 0 && BJ % (16 * WJ) == 0 && BK % 32 == 0, "tile shape");
 };
+
+// s_waitcnt vmcnt(n) for a run-time (wave-uniform) n: the instruction needs an immediate
+V4H_DEV void wait_vmcnt(int n) {
+#define V4H_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    V4H_VM_CASE(0) V4H_VM_CASE(1) V4H_VM_CASE(2) V4H_VM_CASE(3) V4H_VM_CASE(4) V4H_VM_CASE(5) V4H_VM_CASE(6) V4H_VM_CASE(7) V4H_VM_CASE(8)
+    V4H_VM_CASE(9) V4H_VM_CASE(10) V4H_VM_CASE(11) V4H_VM_CASE(12) V4H_VM_CASE(13) V4H_VM_CASE(14) V4H_VM_CASE(15) V4H_VM_CASE(16)
+    V4H_VM_CASE(17) V4H_VM_CASE(18) V4H_VM_CASE(19) V4H_VM_CASE(20) V4H_VM_CASE(21) V4H_VM_CASE(22) V4H_VM_CASE(23) V4H_VM_CASE(24)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef V4H_VM_CASE
+}
 
 // 4-wave workgroups must fit two per CU (2 waves / SIMD, i.e. <= 256 VGPR+AGPR): several epilogue variants sit just above that
 // and would silently halve their occupancy.
@@ -405,7 +421,8 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
   typename C::ImgP stP;
   typename C::ImgQ stQ;
   int ti, tj, tz;
-  bool staged = false;  // tile 0 of the current virtual id already in flight / landed in buffer 0
+  bool staged = false;  // first K-tile(s) of the current virtual id already in flight / landed (issued before the previous epilogue)
+  int pre_issued = 0;   // how many (ring path)
   for (int v = blockIdx.x; decode(v, ti, tj, tz); v += gridDim.x) {
   const int i0 = ti * C::BI, j0 = tj * C::BJ;
   const int kb = tz * a.klen;
@@ -416,12 +433,6 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     stP.stage(smem + buf * BUF_BYTES, k0, ke, a.ldp, wave);
     stQ.stage(smem + buf * BUF_BYTES + C::P_BYTES, k0, ke, a.ldq, wave);
   };
-  if (!staged) {
-    stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
-    stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
-    if (nt > 0) stage(0, 0);
-  }
-
   f32x4 acc[C::TI][C::TJ];
 #pragma unroll
   for (int x = 0; x < C::TI; ++x)
@@ -431,12 +442,8 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
 #pragma unroll
   for (int x = 0; x < C::TI; ++x) cs[x] = 0.f;
 
-  __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
-
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt && (C::DBG != 2)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
-    const char* tp = smem + cur * BUF_BYTES;
+  auto compute = [&](int buf) {
+    const char* tp = smem + buf * BUF_BYTES;
     const char* tq = tp + C::P_BYTES;
 #pragma unroll
     for (int kk = 0; kk < (C::DBG == 1 ? 0 : C::BK); kk += 32) {
@@ -456,19 +463,61 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
 #pragma unroll
         for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);  // (s_setprio around the cluster measured 40 % slower here)
     }
-    __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading the current one
+  };
+
+  if constexpr (C::NSTAGE == 2) {
+    if (!staged) {
+      stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
+      stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
+      if (nt > 0) stage(0, 0);
+    }
+    __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
+    for (int t = 0; t < nt; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < nt && (C::DBG != 2)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
+      compute(cur);
+      __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading the current one
+    }
+  } else {
+    // 4-deep LDS ring, three K-tiles in flight.  Before the barrier of step t a wave waits only until ITS DMA pieces of
+    // tile t have landed (counted vmcnt: the younger tiles stay in flight), the barrier then makes every wave's pieces
+    // visible; tile t+3 is issued right after the barrier into the buffer tile t-1 was read from.
+    const int cnt = C::ImgP::count(wave) + C::ImgQ::count(wave);
+    int issued = staged ? pre_issued : 0;
+    bool drain_all = staged;  // the previous tile's epilogue loads/stores sit behind the prefetch in the vmcnt queue
+    if (!staged) {
+      stP.init(gP, a.ldp, i0, kb, a.I, wave, lane);
+      stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
+      while (issued < nt && issued < 3) { stage(issued, issued); ++issued; }
+    }
+    for (int t = 0; t < nt; ++t) {
+      if (drain_all) {
+        wait_vmcnt(0);
+        drain_all = false;
+      } else {
+        wait_vmcnt((issued - 1 - t) * cnt);
+      }
+      __builtin_amdgcn_s_barrier();
+      while (issued < nt && issued <= t + 3) { stage(issued, issued & 3); ++issued; }
+      compute(t & 3);
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the ring before the epilogue strips / next prefetch overwrite it
   }
 
-  // Prefetch the first K-slab of this workgroup's NEXT output tile into buffer 0 before the epilogue (strips use buffer 1).
+  // Prefetch the first K-tile(s) of this workgroup's NEXT output tile before the epilogue: buffer 0 (2-stage) or buffers
+  // 0 and 1 (ring); the epilogue strips live in the remaining buffers.
   {
     int nti_, ntj_, ntz_;
     staged = false;
     if (C::EPI != EPI_ATOMIC_F32 && a.nz == 1 && decode(v + gridDim.x, nti_, ntj_, ntz_)) {
       stP.init(gP, a.ldp, nti_ * C::BI, 0, a.I, wave, lane);
       stQ.init(gQ, a.ldq, ntj_ * C::BJ, 0, a.J, wave, lane);
-      if (a.K > 0) {
-        stP.stage(smem, 0, a.K, a.ldp, wave);
-        stQ.stage(smem + C::P_BYTES, 0, a.K, a.ldq, wave);
+      const int ntn = (a.K + C::BK - 1) / C::BK;
+      pre_issued = 0;
+      for (int t = 0; t < (C::NSTAGE == 2 ? 1 : 2) && t < ntn; ++t) {
+        stP.stage(smem + t * BUF_BYTES, t * C::BK, a.K, a.ldp, wave);
+        stQ.stage(smem + t * BUF_BYTES + C::P_BYTES, t * C::BK, a.K, a.ldq, wave);
+        ++pre_issued;
       }
       staged = true;
     }
@@ -513,8 +562,9 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     constexpr int SLD = C::WTJ + 4, CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
     using Epi = Epilogue<C::EPI, T, typename C::TO>;
     static_assert(C::WTJ % 8 == 0, "wave tile width must be a multiple of 8");
-    static_assert(C::NW * 16 * SLD * sizeof(float) <= BUF_BYTES, "epilogue staging strip must fit one operand buffer");
-    float* strip = reinterpret_cast<float*>(smem + BUF_BYTES) + wave * (16 * SLD);
+    constexpr int STRIP_OFF = (C::NSTAGE / 2) * BUF_BYTES;  // buffers not targeted by the prefetch above
+    static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES - STRIP_OFF, "epilogue staging strips must fit the free half of the ring");
+    float* strip = reinterpret_cast<float*>(smem + STRIP_OFF) + wave * (16 * SLD);
     const int jb = j0 + wj * C::WTJ;
     int rrow[NIT], rcol[NIT];
     bool cok[NIT];

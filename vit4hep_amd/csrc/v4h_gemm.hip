@@ -7,8 +7,12 @@ namespace {
 // K-step: 64 for bf16 (128-byte rows = whole cache lines per DMA row, half the barriers), 32 for f32 (also 128-byte rows)
 template <typename T> constexpr int bk_of() { return sizeof(T) == 2 ? 64 : 32; }
 
+int g_ring = 0;  // tuning hook: 0 = two buffers x BK 64, 1 = four-deep ring x BK 32 (bf16)
 template <typename T, typename TO, bool PKS, bool QKS, int BI, int BJ, int EPI, bool CS = false>
 int run(const GemmArgs& a, int splitk, hipStream_t s, const char* name) {
+  if constexpr (sizeof(T) == 2) {
+    if (g_ring) return v4h_gemm_launch<GemmCfg<T, TO, PKS, QKS, BI, BJ, 32, 2, 2, EPI, CS, 0, 4>>(a, splitk, s, name);
+  }
   return v4h_gemm_launch<GemmCfg<T, TO, PKS, QKS, BI, BJ, bk_of<T>(), 2, 2, EPI, CS>>(a, splitk, s, name);
 }
 
@@ -18,6 +22,9 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_
   GemmArgs a = a0;
   a.stagger_sleeps = g_stagger;
   if constexpr (sizeof(T) == 2) {
+    if (g_cfg == 0 && g_ring) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false, 0, 4>>(a, 1, s, name);
+    if (g_cfg == 20) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
+    if (g_cfg == 21) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false, 4, 4>>(a, 1, s, name);
     switch (g_cfg) {
       case 2: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
       case 4: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 96, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
@@ -48,7 +55,8 @@ template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (g_cfg_wgrad == 7) return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 160, 32, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
+    if (g_cfg_wgrad == 7) return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 160, 32, 2, 2, EPI_ATOMIC_F32, true, 0, 4>>(a, splitk, s, "gemm_wgrad");
+    if (g_cfg_wgrad == 8) return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 32, 2, 2, EPI_ATOMIC_F32, true, 0, 4>>(a, splitk, s, "gemm_wgrad");
     return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 64, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
   }
   return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 32, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");

@@ -3,6 +3,7 @@
 // C ABI of include/vit4hep_hip.h.  No device allocation, no synchronisation: everything is enqueued on the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -37,7 +38,38 @@ struct v4h_plan {
   int nparams() const { return (int)rows.size(); }
   int blk(int i, int k) const { return P_BLOCK0 + B_COUNT * i + k; }
   int fin(int k) const { return P_BLOCK0 + B_COUNT * depth + k; }
+  // Side stream for the weight-gradient contractions of the backward pass (created on first use): wgrad and dgrad of a
+  // Linear both consume dY and are independent, so they run concurrently and fill each other's idle CUs / tile tails.
+  // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev[8] = {};
+  mutable int evi = 0;
+  mutable bool side_ok = false;
 };
+
+static bool g_overlap_wgrad = true;  // V4H_WGRAD_OVERLAP=0 disables the side stream
+static int side_init(const v4h_plan& p) {
+  if (p.side_ok) return V4H_OK;
+  const char* e = getenv("V4H_WGRAD_OVERLAP");
+  if (e && e[0] == '0') g_overlap_wgrad = false;
+  if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
+  for (int i = 0; i < 8; ++i)
+    if (hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
+  p.side_ok = true;
+  return V4H_OK;
+}
+// the side stream waits for everything enqueued on the main stream so far
+static int side_wait_main(const v4h_plan& p, hipStream_t main) {
+  hipEvent_t e = p.ev[p.evi++ & 7];
+  if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(p.side, e, 0) != hipSuccess) { v4h_set_error("fork failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
+// the main stream waits for everything enqueued on the side stream so far
+static int main_wait_side(const v4h_plan& p, hipStream_t main) {
+  hipEvent_t e = p.ev[p.evi++ & 7];
+  if (hipEventRecord(e, p.side) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) { v4h_set_error("join failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -88,7 +120,13 @@ extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) {
   *out = p;
   return V4H_OK;
 }
-extern "C" void v4h_plan_destroy(v4h_plan* p) { delete p; }
+extern "C" void v4h_plan_destroy(v4h_plan* p) {
+  if (p && p->side_ok) {
+    for (int i = 0; i < 8; ++i) hipEventDestroy(p->ev[i]);
+    hipStreamDestroy(p->side);
+  }
+  delete p;
+}
 extern "C" int32_t v4h_plan_num_params(const v4h_plan* p) { return p ? p->nparams() : 0; }
 extern "C" int32_t v4h_plan_param_shape(const v4h_plan* p, int32_t i, int32_t* r, int32_t* c) {
   V4H_CHECK_ARG(p && i >= 0 && i < p->nparams(), "param_shape: bad index %d", i);
@@ -246,10 +284,10 @@ static int wgrad_splitk(int I, int J, int K) {
   return sk < 1 ? 1 : sk;
 }
 // dW[I][J] += dY^T X  (+ db[I] += column sums of dY)
-static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db) {
+static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db, hipStream_t s = nullptr) {
   GemmArgs a = gargs(dY, ld_dy, X, ld_x, I, J, K);
   a.e.out = dW; a.e.ldo = ldo; a.colsum = db;
-  return gemm_wgrad(c.p.mode, a, wgrad_splitk(I, J, K), c.s);
+  return gemm_wgrad(c.p.mode, a, wgrad_splitk(I, J, K), s ? s : c.s);
 }
 
 static int check_common(const v4h_plan* p, int B, const void* const* params, void* ws, size_t ws_bytes, bool training, const char* who) {
@@ -378,6 +416,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
   const WS& w = c.w;
   const Mode m = p->mode;
   const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
+  RUN(side_init(*p));
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
   auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
 
@@ -406,15 +445,20 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       float* dx_in = dxbuf(2 * j);        // grad wrt X[i+1]
       float* dx_mid = dxbuf(2 * j + 1);   // grad wrt x_mid
       float* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
+      const bool ov = g_overlap_wgrad;
+      hipStream_t ws_ = ov ? p->side : c.s;  // stream of the weight-gradient contractions
       // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
-      RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)]));
+      if (ov) RUN(side_wait_main(*p, c.s));  // dy (and h) ready
+      RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_));
       GemmArgs a = gargs(w.dy, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
       a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
       RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
-      RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)]));
+      if (ov) RUN(side_wait_main(*p, c.s));  // dhpre ready
+      RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_));
       a = gargs(w.dhpre, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      if (ov) RUN(main_wait_side(*p, c.s));  // the next kernel overwrites dy
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = 6 * D;
@@ -423,15 +467,18 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
-      RUN(wgrad(c, w.dy, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)]));
+      if (ov) RUN(side_wait_main(*p, c.s));  // dy ready
+      RUN(wgrad(c, w.dy, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_));
       a = gargs(w.dy, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
       a.e.out = w.dof; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
       RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, w.dqkv, B, T, p->H, p->DH, c.s));
-      RUN(wgrad(c, w.dqkv, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)]));
+      if (ov) RUN(side_wait_main(*p, c.s));  // dqkv ready
+      RUN(wgrad(c, w.dqkv, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_));
       a = gargs(w.dqkv, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      if (ov) RUN(main_wait_side(*p, c.s));  // the next kernel overwrites dy; the stage's gradients are complete after it
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = 6 * D;
       l.dx_in = dx_mid; l.dshift = w.dmod[i]; l.dscale = w.dmod[i] + D; l.ld_dmod = 6 * D;
