@@ -362,6 +362,15 @@ __global__ void rk4_combine_kernel(float* __restrict__ y, const float* __restric
     y[i] += (k1[i] + 3.0f * (k2[i] + k3[i]) + k4[i]) * (h * 0.125f);
 }
 
+// out[k] += sum_z slab[z][k]: the second half of a split-K weight gradient (deterministic, unlike float atomics)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n4, float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 acc = load4(out + 4 * i);
+    for (int z = 0; z < nz; ++z) acc += load4(slab + ((long)z * n4 + i) * 4);
+    store4(out + 4 * i, acc);
+  }
+}
+
 inline int nblocks(long n, int per_block, int cap = 2048) {
   long b = (n + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -496,6 +505,12 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
                float bc1, float bc2, hipStream_t s) {
   hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
   V4H_CHECK_LAUNCH("adamw");
+  return V4H_OK;
+}
+int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s) {
+  V4H_CHECK_ARG(n % 4 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)slab % 16) == 0, "slab_reduce: size / alignment");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
+  V4H_CHECK_LAUNCH("slab_reduce");
   return V4H_OK;
 }
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s) {

@@ -33,6 +33,7 @@ enum : int {
   EPI_ATOMIC_F32,     // atomicAdd(out(f32)[i][j], acc)
   EPI_ACCUM_F32,      // out(f32)[i][j] += acc
   EPI_UNPATCH,        // voxel scatter: out(f32)[b, voxel(n, f=j)] = acc + bias[j]  (final linear + from_patches)
+  EPI_SLAB_F32,       // split-K partial: out(f32)[z][i][j] = acc (plain stores; summed afterwards by slab_reduce)
 };
 
 struct PatchGeom {  // CaloChallengeCFM.to_patches / from_patches  (calochallenge_cfm/model.py:40-60), C = 1
@@ -51,6 +52,7 @@ struct EpiArgs {
   const void* aux; int ld_aux;          // TO-typed auxiliary (pre-activation for gelu')
   const float* auxf; int ld_auxf;       // f32 auxiliary
   PatchGeom pg; int P;                  // EPI_UNPATCH: real patch_dim (columns >= P are padding)
+  long slab_stride;                     // EPI_SLAB_F32: elements between the partial results of consecutive K splits
 };
 
 struct GemmArgs {
@@ -106,7 +108,7 @@ V4H_DEV f32x8 add8(f32x8 a, const f32x8& b) {
 // in-order queue, so a load waited for after a store would drain that store's whole round trip.
 template <int EPI, typename T, typename TO> struct Epilogue {
   struct Ops { f32x8 a, b; };
-  static constexpr bool HAS_BIAS = EPI != EPI_DGELU && EPI != EPI_DSILU && EPI != EPI_ATOMIC_F32 && EPI != EPI_ACCUM_F32;
+  static constexpr bool HAS_BIAS = EPI != EPI_DGELU && EPI != EPI_DSILU && EPI != EPI_ATOMIC_F32 && EPI != EPI_ACCUM_F32 && EPI != EPI_SLAB_F32;
 
   static V4H_DEV Ops load(const EpiArgs& e, int i, int j) {
     Ops o;
@@ -131,7 +133,7 @@ template <int EPI, typename T, typename TO> struct Epilogue {
   static V4H_DEV void finish(const EpiArgs& e, int i, int j, f32x8 v, const Ops& o) {
     if constexpr (EPI == EPI_STORE) {
       store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
-    } else if constexpr (EPI == EPI_STORE_F32) {
+    } else if constexpr (EPI == EPI_STORE_F32 || EPI == EPI_SLAB_F32) {
       store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, v);
     } else if constexpr (EPI == EPI_SILU) {
       if (e.out2) store8(reinterpret_cast<float*>(e.out2) + (size_t)i * e.ldo2 + j, v);
@@ -561,6 +563,8 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     // for the output and for every epilogue operand (bias, residual, gate, pre-activation).
     constexpr int SLD = C::WTJ + 4, CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
     using Epi = Epilogue<C::EPI, T, typename C::TO>;
+    EpiArgs ea = a.e;
+    if constexpr (C::EPI == EPI_SLAB_F32) ea.out = reinterpret_cast<float*>(a.e.out) + (size_t)tz * a.e.slab_stride;
     static_assert(C::WTJ % 8 == 0, "wave tile width must be a multiple of 8");
     constexpr int STRIP_OFF = (C::NSTAGE / 2) * BUF_BYTES;  // buffers not targeted by the prefetch above
     static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES - STRIP_OFF, "epilogue staging strips must fit the free half of the ring");
@@ -595,12 +599,12 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         if (cok[it] && ib + rrow[it] < a.I) {
           v[it] = add8(make8(*reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it]),
                              *reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it] + 4)), bias8[it]);
-          ops[it] = Epi::load(a.e, ib + rrow[it], jb + rcol[it]);
+          ops[it] = Epi::load(ea, ib + rrow[it], jb + rcol[it]);
         }
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {  // phase 2: math + stores
-        if (cok[it] && ib + rrow[it] < a.I) Epi::finish(a.e, ib + rrow[it], jb + rcol[it], v[it], ops[it]);
+        if (cok[it] && ib + rrow[it] < a.I) Epi::finish(ea, ib + rrow[it], jb + rcol[it], v[it], ops[it]);
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
@@ -630,7 +634,7 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
   V4H_CHECK_ARG(C::QKS ? (a.J % CH == 0) : (a.K % CH == 0), "%s: Q extent not a whole number of 16-byte chunks", name);
   V4H_CHECK_ARG(((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0, "%s: operands must be 16-byte aligned", name);
   if (splitk < 1) splitk = 1;
-  if (C::EPI != EPI_ATOMIC_F32) splitk = 1;
+  if (C::EPI != EPI_ATOMIC_F32 && C::EPI != EPI_SLAB_F32) splitk = 1;
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + C::BK - 1) / C::BK * C::BK;
   a.klen = klen;

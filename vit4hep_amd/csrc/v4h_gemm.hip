@@ -97,6 +97,17 @@ int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk) { 
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s) {
   return m == MODE_BF16 ? run_wgrad_cfg<bf16>(a, splitk, s) : run_wgrad_cfg<float>(a, splitk, s);
 }
+// split-K partials into a slab [nz][I][J] with plain stores; returns the number of splits actually used in *nz_out
+int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz_out, hipStream_t s) {
+  GemmArgs a = a0;
+  a.e.out = slab; a.e.ldo = a.J; a.e.slab_stride = (long)a.I * a.J;
+  const int bk = m == MODE_BF16 ? 64 : 32;
+  int klen = (a.K + splitk - 1) / splitk;
+  klen = (klen + bk - 1) / bk * bk;
+  *nz_out = (a.K + klen - 1) / klen;
+  if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 160, 96, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
+  return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
+}
 
 void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad; }
 
