@@ -216,45 +216,73 @@ template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_mod
       if (y) gt[n] = load4(a.gate + (long)b * a.ld_mod_gate + c);
     }
   }
-  for (int t = t0 + wave; t < t1; t += 4) {
-    const long row = (long)b * a.T + t;
-    const float mu = a.mean[row], rs = a.rstd[row];
-    f32x4 gy[LN_MAXV], xh[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  // two token rows per iteration: all loads of both rows are issued before the first reduction (memory-level parallelism)
+  constexpr int R = 2;
+  for (int tb = t0 + wave * R; tb < t1; tb += 4 * R) {
+    long row[R];
+    bool ok[R];
+    float mu[R], rs[R], s1[R], s2[R];
+    f32x4 gy[R][LN_MAXV], xh[R][LN_MAXV], dxi[R][LN_MAXV], yv[R][LN_MAXV];
 #pragma unroll
-    for (int n = 0; n < LN_MAXV; ++n) {
-      const int c = lane * 4 + 256 * n;
-      gy[n] = xh[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < D) {
-        const f32x4 d = load4(du + row * D + c);
-        const f32x4 xv = load4(a.x + row * D + c);
+    for (int q = 0; q < R; ++q) {
+      ok[q] = tb + q < t1;
+      row[q] = (long)b * a.T + (ok[q] ? tb + q : t0);
+      mu[q] = a.mean[row[q]];
+      rs[q] = a.rstd[row[q]];
+      s1[q] = s2[q] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          xh[n][r] = (xv[r] - mu) * rs;
-          gy[n][r] = d[r] * (1.0f + sc[n][r]);
-          acc_sh[n][r] += d[r];
-          acc_sc[n][r] += d[r] * xh[n][r];
-          s1 += gy[n][r];
-          s2 += gy[n][r] * xh[n][r];
+      for (int n = 0; n < LN_MAXV; ++n) {
+        const int c = lane * 4 + 256 * n;
+        gy[q][n] = xh[q][n] = dxi[q][n] = yv[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D && ok[q]) {
+          gy[q][n] = load4(du + row[q] * D + c);  // holds du for now
+          xh[q][n] = load4(a.x + row[q] * D + c);  // holds x for now
+          if (a.dx_in) dxi[q][n] = load4(a.dx_in + row[q] * D + c);
+          if (y) yv[q][n] = load4(y + row[q] * D + c);
         }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
 #pragma unroll
-    for (int n = 0; n < LN_MAXV; ++n) {
-      const int c = lane * 4 + 256 * n;
-      if (c < D) {
-        f32x4 dx;
+    for (int q = 0; q < R; ++q) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dx[r] = rs * (gy[n][r] - s1 - xh[n][r] * s2);
-        if (a.dx_in) dx += load4(a.dx_in + row * D + c);
-        if (a.dx_out) store4(a.dx_out + row * D + c, dx);
-        if (a.dx_out_t) store4(reinterpret_cast<T*>(a.dx_out_t) + row * D + c, dx);
-        if (y) {
-          const f32x4 yv = load4(y + row * D + c);
-          acc_g[n] += dx * yv;
-          store4(reinterpret_cast<T*>(a.dy) + row * D + c, dx * gt[n]);
+      for (int n = 0; n < LN_MAXV; ++n) {
+        const int c = lane * 4 + 256 * n;
+        if (c < D && ok[q]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = gy[q][n][r];
+            const float xhat = (xh[q][n][r] - mu[q]) * rs[q];
+            xh[q][n][r] = xhat;
+            gy[q][n][r] = d * (1.0f + sc[n][r]);
+            acc_sh[n][r] += d;
+            acc_sc[n][r] += d * xhat;
+            s1[q] += gy[q][n][r];
+            s2[q] += gy[q][n][r] * xhat;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      s1[q] = wave_sum(s1[q]) / (float)D;
+      s2[q] = wave_sum(s2[q]) / (float)D;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+#pragma unroll
+      for (int n = 0; n < LN_MAXV; ++n) {
+        const int c = lane * 4 + 256 * n;
+        if (c < D && ok[q]) {
+          f32x4 dx;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dx[r] = rs[q] * (gy[q][n][r] - s1[q] - xh[q][n][r] * s2[q]);
+          dx += dxi[q][n];
+          if (a.dx_out) store4(a.dx_out + row[q] * D + c, dx);
+          if (a.dx_out_t) store4(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
+          if (y) {
+            acc_g[n] += dx * yv[q][n];
+            store4(reinterpret_cast<T*>(a.dy) + row[q] * D + c, dx * gt[n]);
+          }
         }
       }
     }

@@ -158,7 +158,7 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       f32x8 d;
 #pragma unroll
       for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
-      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);
+      if (e.out) store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);  // derivative only kept for the backward
       store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
     } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll

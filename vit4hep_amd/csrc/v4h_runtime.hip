@@ -394,7 +394,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
     RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, 6 * D, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
     a = gargs(b.u2, D, c.W(p->blk(i, B_FC1W)), D, BT, M, D);
-    a.e.out = b.hgrad; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M;  /* hgrad = gelu_tanh'(fc1 output), h = gelu_tanh(fc1 output) */ a.e.bias = c.pf(p->blk(i, B_FC1B));
+    a.e.out = training ? b.hgrad : nullptr; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M;  /* hgrad = gelu_tanh'(fc1 output), h = gelu_tanh(fc1 output) */ a.e.bias = c.pf(p->blk(i, B_FC1B));
     RUN(gemm_fwd(m, EPI_GELU, a, c.s));
     a = gargs(b.h, M, c.W(p->blk(i, B_FC2W)), M, BT, D, M);
     a.e.out = w.X[i + 1]; a.e.ldo = D; a.e.out2 = training ? b.y2 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_FC2B));
