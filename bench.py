@@ -24,6 +24,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# HBM bytes per update step from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_step.sh; FETCH_SIZE doubled
+# per MI355X_MICROARCH.md because the reads are 16-byte-per-lane streams, WRITE_SIZE as is): profiles/r01_step_hbm_traffic.txt
+MEASURED_HBM_BYTES_PER_STEP = {("ds2", "bf16"): 2 * 4.879e9 + 5.130e9}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector rate
 
@@ -210,7 +213,7 @@ def main():
                        "params": sum(p.numel() for p in model.parameters()), "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
             "loss": round(float(loss), 5),
             "grad_norm": round(float(gn), 5),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": MEASURED_HBM_BYTES_PER_STEP.get((args.workload, args.mode)),
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
