@@ -268,16 +268,25 @@ template <typename T, int ROWS, int BK, int NW> struct ImgKContig {
   }
   // stage the tile starting at k0 into img, then advance to the next tile
   V4H_DEV void stage(char* img, int k0, int k_end, int ld, int wave) {
-    const bool full = k0 + BK <= k_end;  // scalar
+    // steady state (whole tile inside K): nothing but the DMA and one pointer bump per KiB; only the last, partial tile
+    // takes the predicated path.  The branch is on a scalar, so the compiler must not if-convert it into per-lane selects.
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(k0 + BK <= k_end)), 1)) {
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-      const int inst = wave + n * NW;
-      if (inst < NI) {
-        const void* p = src[n];
-        if (!full && k0 + koff[n] + CH > k_end) p = v4h_zero_page;
-        dma16(p, img + inst * 1024);
+      for (int n = 0; n < NPW; ++n) {
+        const int inst = wave + n * NW;
+        if (inst < NI) dma16(src[n], img + inst * 1024);
+        src[n] += BK * sizeof(T);
       }
-      src[n] += BK * sizeof(T);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) {
+        const int inst = wave + n * NW;
+        if (inst < NI) {
+          const void* p = (k0 + koff[n] + CH > k_end) ? (const void*)v4h_zero_page : (const void*)src[n];
+          dma16(p, img + inst * 1024);
+        }
+        src[n] += BK * sizeof(T);
+      }
     }
   }
   // canonical fragment of rows idx0.. , K slab kk..kk+31
@@ -316,16 +325,24 @@ template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
     }
   }
   V4H_DEV void stage(char* img, int k0, int k_end, int ld, int wave) {
-    const bool full = k0 + BK <= k_end;
+    const size_t bump = (size_t)BK * ld * sizeof(T);
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)(k0 + BK <= k_end)), 1)) {
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) {
-      const int inst = wave + n * NW;
-      if (inst < NI) {
-        const void* p = src[n];
-        if (!full && k0 + krow[n] >= k_end) p = v4h_zero_page;
-        dma16(p, img + inst * 1024);
+      for (int n = 0; n < NPW; ++n) {
+        const int inst = wave + n * NW;
+        if (inst < NI) dma16(src[n], img + inst * 1024);
+        src[n] += bump;
       }
-      src[n] += (size_t)BK * ld * sizeof(T);
+    } else {
+#pragma unroll
+      for (int n = 0; n < NPW; ++n) {
+        const int inst = wave + n * NW;
+        if (inst < NI) {
+          const void* p = (k0 + krow[n] >= k_end) ? (const void*)v4h_zero_page : (const void*)src[n];
+          dma16(p, img + inst * 1024);
+        }
+        src[n] += bump;
+      }
     }
   }
   static V4H_DEV Frag<T> frag(const char* img, int idx0, int kk, int lane) {
