@@ -74,10 +74,13 @@ def load():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} not found: build it with `python -m vit4hep_amd.build` (hipcc, gfx950). "
-            "vit4hep_amd has no CPU or PyTorch fallback for the ViT-CFM path."
-        )
+        try:  # fresh checkout (the .so is git-ignored): compile it in-tree; rank 0 of a multi-process job builds, the others wait
+            _build_once()
+        except Exception as e:
+            raise RuntimeError(
+                f"{LIB_PATH} not found and could not be built ({e}): run `python -m vit4hep_amd.build` (hipcc, gfx950). "
+                "vit4hep_amd has no CPU or PyTorch fallback for the ViT-CFM path."
+            ) from e
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
@@ -87,6 +90,27 @@ def load():
         raise RuntimeError(f"libvit4hep_hip.so ABI {lib.v4h_abi_version()} != 1")
     _lib = lib
     return lib
+
+
+def _build_once():
+    import time
+
+    from .build import build
+
+    lock = LIB_PATH + ".lock"
+    try:
+        fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+    except FileExistsError:  # another local rank is compiling
+        for _ in range(600):
+            if os.path.exists(LIB_PATH) and not os.path.exists(lock):
+                return
+            time.sleep(1.0)
+        raise RuntimeError("timed out waiting for another process to build the library")
+    try:
+        os.close(fd)
+        build(verbose=False)
+    finally:
+        os.remove(lock)
 
 
 def check(rc, what=""):

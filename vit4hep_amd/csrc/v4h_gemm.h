@@ -465,7 +465,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     const char* tp = smem + buf * BUF_BYTES;
     const char* tq = tp + C::P_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < (C::DBG == 1 ? 0 : C::BK); kk += 32) {
+    for (int kk = 0; kk < (C::DBG == 1 ? 0 : C::BK); kk += 32) {  // DBG 1: staging only
       Frag<T> pf[C::TI], qf[C::TJ];
 #pragma unroll
       for (int x = 0; x < C::TI; ++x) pf[x] = C::ImgP::frag(tp, wi * C::WTI + x * 16, kk, lane);
@@ -493,7 +493,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
-      if (t + 1 < nt && (C::DBG != 2)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
+      if (t + 1 < nt && (C::DBG != 2) && (C::DBG != 5)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
       compute(cur);
       __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading the current one
     }
@@ -564,7 +564,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
       }
       __syncthreads();
     }
-  } else if constexpr (C::DBG == 4) {
+  } else if constexpr (C::DBG == 4 || C::DBG == 5) {
     // ablation (tools/gemm_bench.py): keep every MFMA live but write 16 bytes per lane per tile instead of the whole tile
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -34,6 +34,7 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_
       case 9: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 2>>(a, 1, s, name);
       case 13: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
       case 14: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
+      case 16: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 5>>(a, 1, s, name);
       case 15: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 4>>(a, 1, s, name);
       case 12: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
       case 10: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 160, 64, 4, 2, EPI_STORE, false, 1>>(a, 1, s, name);
