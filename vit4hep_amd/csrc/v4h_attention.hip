@@ -14,6 +14,8 @@
 // the contraction by zeroing fragment lanes, never in memory.
 #include "v4h_common.h"
 #include "v4h_gemm.h"  // TileStage
+#include <stdlib.h>
+
 #include "v4h_ops.h"
 
 namespace {
@@ -167,6 +169,112 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) store4(orow + dt * 16 + 4 * g, oacc[dt] * inv);
       if (g == 0 && lse) lse[((size_t)b * H + h) * Tn + q] = m + __logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- forward, persistent
+// Single-chunk case (T <= 160, i.e. ds2): a persistent workgroup walks (batch, head) items id, id + grid, ... and DMAs the NEXT
+// item's K and V (global_load_lds, dense 160-byte rows, rows >= T from the zero page) into the other LDS buffer while it
+// computes the current one, so the load -> compute serialisation of the one-shot kernel disappears.  One barrier per item.
+template <typename T, int DH> struct AttnDense {
+  static constexpr int CPRD = DH * (int)sizeof(T) / 16;        // 16-byte chunks per row
+  static constexpr int UNITS = KC * CPRD, NI = (UNITS + 63) / 64;
+  static constexpr int BYTES = NI * 1024;                       // whole DMA instructions
+  // stage rows [0, KC) x DH of a token-major tensor (row stride ld elements) into a dense image
+  static V4H_DEV void stage(char* img, const T* base, int ld, int rows_end, int wave, int nw, int lane) {
+    for (int inst = wave; inst < NI; inst += nw) {
+      const int u = inst * 64 + lane, row = u / CPRD, ch = u % CPRD;
+      const void* src = (u < UNITS && row < rows_end) ? (const void*)(base + (size_t)row * ld + ch * (16 / (int)sizeof(T))) : (const void*)v4h_zero_page;
+      dma16(src, img + inst * 1024);
+    }
+  }
+};
+
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_fwd_persist_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                                                                     float* __restrict__ lse, int Tn, int H, int nitems,
+                                                                                                     float scale) {
+  using C = AttnCfg<T, DH>;
+  using DI = AttnDense<T, DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K0 | V0 | K1 | V1]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * DH, ld = 3 * D;
+  const int ntiles = (Tn + 15) / 16;
+  const bool active = wave < ntiles;
+  auto item_base = [&](int it) { return qkv + (size_t)(it / H) * Tn * ld + (it % H) * DH; };
+  auto stage_item = [&](int it, int buf) {
+    const T* base = item_base(it);
+    DI::stage(smem + buf * 2 * DI::BYTES, base + D, ld, Tn, wave, NW, lane);
+    DI::stage(smem + buf * 2 * DI::BYTES + DI::BYTES, base + 2 * D, ld, Tn, wave, NW, lane);
+  };
+  int it = blockIdx.x;
+  Frag<T> xq[C::NKF], xq_next[C::NKF];  // this wave's 16 query rows: current item, and the next one (fetched a whole item ahead)
+  if (it < nitems) {
+    stage_item(it, 0);
+    load_row_frags<T, DH>(xq_next, item_base(it), ld, wave * 16, active ? Tn : 0, lane);
+  }
+  for (int n = 0; it < nitems; it += gridDim.x, ++n) {
+    const int buf = n & 1;
+#pragma unroll
+    for (int s2 = 0; s2 < C::NKF; ++s2) xq[s2] = xq_next[s2];
+    __syncthreads();  // this item's K/V landed (vmcnt(0)); everyone is done with the buffer the next DMA overwrites
+    if (it + gridDim.x < nitems) {
+      stage_item(it + gridDim.x, buf ^ 1);
+      load_row_frags<T, DH>(xq_next, item_base(it + gridDim.x), ld, wave * 16, active ? Tn : 0, lane);
+    }
+    if (active) {
+      const T* sK = reinterpret_cast<const T*>(smem + buf * 2 * DI::BYTES);
+      const T* sV = reinterpret_cast<const T*>(smem + buf * 2 * DI::BYTES + DI::BYTES);
+      const int b = it / H, h = it % H;
+      f32x4 p[C::NJT];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < C::NJT; ++jt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < C::NKF; ++s2) {
+          Frag<T> kf = frag_kcontig(sK, DH, jt * 16, 32 * s2, lane);
+          if (32 * s2 + 8 * g + 8 > DH) kf = frag_zero<T>();
+          a = mma(kf, xq[s2], a);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = jt * 16 + 4 * g + r;
+          a[r] = key < Tn ? a[r] * scale : -INFINITY;
+          mx = fmaxf(mx, a[r]);
+        }
+        p[jt] = a;
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float rs = 0.f;
+#pragma unroll
+      for (int jt = 0; jt < C::NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[jt][r] = __expf(p[jt][r] - mx);
+          rs += p[jt][r];
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      f32x4 oacc[C::NDT];
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::NJT / 2; ++ks) {
+        const Frag<T> wf = frag_from_acc(p[2 * ks], p[2 * ks + 1], T());
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = mma(frag_kstrided2(sV, DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
+      }
+      const int q = wave * 16 + c;
+      if (q < Tn) {
+        const float inv = 1.0f / rs;
+        T* orow = o + ((size_t)b * Tn + q) * D + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) store4(orow + dt * 16 + 4 * g, oacc[dt] * inv);
+        if (g == 0 && lse) lse[((size_t)b * H + h) * Tn + q] = mx + __logf(rs);
+      }
     }
   }
 }
@@ -360,6 +468,20 @@ template <typename T, int NW> int attn_fwd_launch(const void* qkv, void* o, floa
 template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
   V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80 = 480/6, every shipped shape-CFM config)", DH);
   const int ntiles = (Tn + 15) / 16;
+  if constexpr (sizeof(T) == 2) {
+    static const bool persist = !(getenv("V4H_ATTN_PERSIST") && getenv("V4H_ATTN_PERSIST")[0] == '0');
+    if (persist && Tn <= KC && ntiles <= 9) {  // single key chunk: persistent, double-buffered K/V
+      constexpr int NW = 9;
+      const size_t lds = 4 * (size_t)AttnDense<T, 80>::BYTES + 64;
+      int rc = set_lds(attn_fwd_persist_kernel<T, 80, NW>, lds, "attn_fwd_persist");
+      if (rc) return rc;
+      const int nitems = B * H;
+      hipLaunchKernelGGL((attn_fwd_persist_kernel<T, 80, NW>), dim3(nitems < 256 ? nitems : 256), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, nitems,
+                         1.0f / sqrtf((float)DH));
+      V4H_CHECK_LAUNCH("attn_fwd_persist");
+      return V4H_OK;
+    }
+  }
   if (sizeof(T) == 4 || ntiles <= 4) return attn_fwd_launch<T, 4>(qkv, o, lse, B, Tn, H, DH, s);  // f32: 8 VGPRs per fragment -> 256-register budget
   if (ntiles % 9 == 0) return attn_fwd_launch<T, 9>(qkv, o, lse, B, Tn, H, DH, s);
   return attn_fwd_launch<T, 8>(qkv, o, lse, B, Tn, H, DH, s);
