@@ -490,7 +490,12 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
       stQ.init(gQ, a.ldq, j0, kb, a.J, wave, lane);
       if (nt > 0) stage(0, 0);
     }
-    __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
+    if (C::DBG == 6 && staged) {  // experiment: leave the previous tile's 12 output stores (younger than the prefetch) in flight
+      wait_vmcnt(12);
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();  // vmcnt(0) + barrier: tile 0 has landed for every wave, previous tile's epilogue strips are dead
+    }
     for (int t = 0; t < nt; ++t) {
       const int cur = t & 1;
       if (t + 1 < nt && (C::DBG != 2) && (C::DBG != 5)) stage(t + 1, cur ^ 1);  // DMA of the next tile flies during this tile's MFMAs
@@ -578,7 +583,8 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     // 8-byte stores into 16 different cache lines.  Instead each wave passes its tile through a private LDS strip, 16 rows
     // at a time, and each lane then owns 8 CONSECUTIVE columns of a row: 16/32-byte accesses, WTJ*sizeof contiguous per row,
     // for the output and for every epilogue operand (bias, residual, gate, pre-activation).
-    constexpr int SLD = C::WTJ + 4, CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
+    constexpr int FREE = (int)C::LDS_BYTES - (C::NSTAGE / 2) * BUF_BYTES;  // strips live in the ring half the prefetch does not touch
+    constexpr int SLD = C::WTJ + ((C::NW * 16 * (C::WTJ + 4) * 4 <= FREE) ? 4 : 0), CPRW = C::WTJ / 8, NCH = 16 * CPRW, NIT = (NCH + 63) / 64;
     using Epi = Epilogue<C::EPI, T, typename C::TO>;
     EpiArgs ea = a.e;
     if constexpr (C::EPI == EPI_SLAB_F32) ea.out = reinterpret_cast<float*>(a.e.out) + (size_t)tz * a.e.slab_stride;

@@ -1,4 +1,6 @@
 // Instantiations + dispatch of the generic contraction (v4h_gemm.h) for the three layouts of a Linear.
+#include <stdlib.h>
+
 #include "v4h_ops.h"
 
 namespace v4h {
@@ -15,6 +17,16 @@ int run(const GemmArgs& a, int splitk, hipStream_t s, const char* name) {
   }
   return v4h_gemm_launch<GemmCfg<T, TO, PKS, QKS, BI, BJ, bk_of<T>(), 2, 2, EPI, CS>>(a, splitk, s, name);
 }
+
+// 256 x 192 tile, 12 waves (4 x 3, wave tile 64 x 64), one workgroup per CU: 110 FLOP per staged byte instead of 71.  Pays when
+// J is a multiple of 192 (N = 1920) or K is long (fc2 forward); loses for a 192-wide K-strided operand (2-way tr-read conflicts).
+static int env_flag(const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; }
+int g_big = env_flag("V4H_GEMM_BIG", 0);  // tuning hook / env: 0 disables
+template <typename T, typename TO, bool QKS, int EPI> int run_big(const GemmArgs& a, hipStream_t s, const char* name) {
+  return v4h_gemm_launch<GemmCfg<T, TO, false, QKS, 256, 192, 64, 4, 3, EPI, false>>(a, 1, s, name);
+}
+inline bool big_fwd(const GemmArgs& a) { return g_big && a.I >= 4096 && (a.J % 192 == 0 || a.K >= 1920); }
+inline bool big_dgrad(const GemmArgs& a) { return g_big && a.I >= 4096 && a.J % 192 == 0 && a.J >= 960; }
 
 // ---- tile-shape tuning hook (tools/gemm_bench.py): selects the configuration used for EPI_STORE fwd/dgrad and wgrad ----
 int g_cfg = 0, g_cfg_wgrad = 0, g_stagger = 0;
@@ -34,6 +46,10 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_
       case 9: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 2>>(a, 1, s, name);
       case 13: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
       case 14: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 128, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
+      case 18: if constexpr (!QKS) return v4h_gemm_launch<GemmCfg<T, T, false, false, 256, 240, 64, 4, 3, EPI_STORE, false>>(a, 1, s, name); else break;
+      case 19: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 3, EPI_STORE, false>>(a, 1, s, name);
+      case 22: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 17: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 6>>(a, 1, s, name);
       case 16: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 5>>(a, 1, s, name);
       case 15: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 4>>(a, 1, s, name);
       case 12: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 3>>(a, 1, s, name);
@@ -70,8 +86,12 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_SILU: return run<T, T, false, false, 128, 160, EPI_SILU>(a, 1, s, "gemm_fwd/silu");
     case EPI_COND_SUM: return run<T, T, false, false, 128, 160, EPI_COND_SUM>(a, 1, s, "gemm_fwd/cond_sum");
     case EPI_EMBED: return run<T, T, false, false, 128, 160, EPI_EMBED>(a, 1, s, "gemm_fwd/embed");
-    case EPI_GATE_RESID: return run<T, T, false, false, 128, 160, EPI_GATE_RESID>(a, 1, s, "gemm_fwd/gate_resid");
-    case EPI_GELU: return run<T, T, false, false, 128, 160, EPI_GELU>(a, 1, s, "gemm_fwd/gelu");
+    case EPI_GATE_RESID:
+      if constexpr (sizeof(T) == 2) { if (big_fwd(a)) return run_big<T, T, false, EPI_GATE_RESID>(a, s, "gemm_fwd/gate_resid/big"); }
+      return run<T, T, false, false, 128, 160, EPI_GATE_RESID>(a, 1, s, "gemm_fwd/gate_resid");
+    case EPI_GELU:
+      if constexpr (sizeof(T) == 2) { if (big_fwd(a)) return run_big<T, T, false, EPI_GELU>(a, s, "gemm_fwd/gelu/big"); }
+      return run<T, T, false, false, 128, 160, EPI_GELU>(a, 1, s, "gemm_fwd/gelu");
     case EPI_UNPATCH: return run<T, T, false, false, 128, 96, EPI_UNPATCH>(a, 1, s, "gemm_fwd/unpatch");
   }
   v4h_set_error("gemm_fwd: epilogue %d not built", epi);
@@ -81,7 +101,9 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
 template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStream_t s) {
   switch (epi) {
     case EPI_STORE: return run_store_cfg<T, true>(a, s, "gemm_dgrad/store");
-    case EPI_DGELU: return run<T, T, false, true, 128, 160, EPI_DGELU>(a, 1, s, "gemm_dgrad/dgelu");
+    case EPI_DGELU:
+      if constexpr (sizeof(T) == 2) { if (big_dgrad(a)) return run_big<T, T, true, EPI_DGELU>(a, s, "gemm_dgrad/dgelu/big"); }
+      return run<T, T, false, true, 128, 160, EPI_DGELU>(a, 1, s, "gemm_dgrad/dgelu");
     case EPI_DSILU: return run<T, T, false, true, 128, 160, EPI_DSILU>(a, 1, s, "gemm_dgrad/dsilu");
     case EPI_ACCUM_F32: return run<T, T, false, true, 128, 160, EPI_ACCUM_F32>(a, 1, s, "gemm_dgrad/accum");
     case EPI_STORE_F32: return run<T, T, false, true, 128, 160, EPI_STORE_F32>(a, 1, s, "gemm_dgrad/store_f32");
@@ -110,6 +132,6 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
 }
 
-void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad; }
+void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad % 100; g_big = cfg_wgrad / 100 ? 0 : 1; }
 
 }  // namespace v4h
