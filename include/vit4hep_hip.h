@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 1
+#define V4H_ABI_VERSION 2
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -47,6 +47,13 @@ const char* v4h_last_error(void);
 
 /* ---- plan ------------------------------------------------------------------------------------------------ */
 int32_t v4h_plan_create(const v4h_config* cfg, v4h_plan** out);
+/* General ("mapped") geometry: any voxel <-> patch-token layout, e.g. the multi-segment patching of CaloChallengeCFM_DS1
+ * (calochallenge_cfm/model.py:97-173), CaloGANCFM (experiments/calogan/model.py:8-86), CaloHadCFM
+ * (experiments/calohadronic/model.py:8-86).  cfg->shape / patch_shape are ignored; a sample is `voxels` consecutive f32
+ * values, the network sees `tokens` tokens of `patch_dim` features.  Every forward / backward call then takes
+ *   d_patch_map : int32 [tokens * patch_dim], voxel index (within the sample) of token n feature f, or -1 for none,
+ *   d_pos       : f32 [3 * tokens] = pos_x | pos_y | pos_z, the buffers of ViT.create_meshgrid (nn/vit.py:137-154). */
+int32_t v4h_plan_create_mapped(const v4h_config* cfg, int32_t tokens, int32_t patch_dim, int64_t voxels, v4h_plan** out);
 void v4h_plan_destroy(v4h_plan* plan);
 /* number of learnable tensors (= 11 + 10*depth + 4) and, for index i, its element count / rows / cols in the
  * reference's state_dict() order (nn/vit.py:76-132: pos_embed_freqs, x_embedder.{weight,bias},
@@ -62,14 +69,15 @@ size_t v4h_plan_workspace_bytes(const v4h_plan* plan, int32_t B, int32_t trainin
 /* d_params: host array of v4h_plan_num_params() device pointers to f32 tensors in the order above.
  * d_x (B,1,L,A,R) f32, d_t (B) f32, d_c (B,condition_dim) f32 -> d_out (B,1,L,A,R) f32. */
 int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
-                        float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream);
+                        float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream, const int32_t* d_patch_map,
+                        const float* d_pos);
 /* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
  * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
  * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce
  * with the remaining backward: stage 0 = final layer, stage 1+j = block depth-1-j, stage depth+1 = embedders
  * (x/t/c embedders + pos_embed_freqs).  Stages must be run in increasing order, each exactly once. */
 int32_t v4h_vit_backward(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout, void* d_workspace,
-                         size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream);
+                         size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream, const int32_t* d_patch_map, const float* d_pos);
 int32_t v4h_vit_num_backward_stages(const v4h_plan* plan);
 
 /* ---- CFM step pieces ------------------------------------------------------------------------------------- */
@@ -100,10 +108,10 @@ int32_t v4h_op_attention_bwd(int32_t mode, const void* d_qkv, const void* d_o, c
 int32_t v4h_op_ln_modulate_fwd(int32_t mode, const float* d_x, const float* d_shift, const float* d_scale, int32_t ld_mod, void* d_u, float* d_mean,
                                float* d_rstd, int32_t B, int32_t T, int32_t D, void* stream);
 /* to_patches / from_patches   calochallenge_cfm/model.py:40-60 ; tokens are f32 (B*T, P) */
-int32_t v4h_op_patchify(const v4h_plan* plan, const float* d_vox, float* d_tokens, int32_t B, void* stream);
-int32_t v4h_op_unpatchify(const v4h_plan* plan, const float* d_tokens, float* d_vox, int32_t B, void* stream);
+int32_t v4h_op_patchify(const v4h_plan* plan, const float* d_vox, float* d_tokens, int32_t B, void* stream, const int32_t* d_patch_map);
+int32_t v4h_op_unpatchify(const v4h_plan* plan, const float* d_tokens, float* d_vox, int32_t B, void* stream, const int32_t* d_patch_map);
 /* learnable_pos_embedding   nn/vit.py:156-162 -> (T, D) f32 */
-int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe, void* stream);
+int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe, void* stream, const float* d_pos);
 
 /* tuning hook (tools/gemm_bench.py only): selects the tile configuration of the plain-store and wgrad contractions */
 void v4h_debug_set_gemm_cfg(int32_t cfg, int32_t cfg_wgrad);

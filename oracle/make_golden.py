@@ -87,11 +87,10 @@ def _install_standins():
     sys.modules["torchdiffeq"] = tde
 
 
-def build_reference(cfg: O.ViTConfig, use_torch_sdpa=True):
+def build_reference(cfg: O.ViTConfig, use_torch_sdpa=True, kind="calochallenge"):
     from experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM
     from nn.vit import ViT
 
-    l, a, r = cfg.num_patches
     param = {
         "dim": 3,
         "condition_dim": cfg.condition_dim,
@@ -107,20 +106,37 @@ def build_reference(cfg: O.ViTConfig, use_torch_sdpa=True):
         "learn_pos_embed": True,
         "causal_attn": False,
         "checkpoint_grads": False,
-        "num_patches": [[l, a, r]],
+        "num_patches": [list(n) for n in cfg.seg_num_patches],
         "patch_dim": cfg.P,
         "use_torch_sdpa": use_torch_sdpa,
     }
     net = ViT(param)
-    model = CaloChallengeCFM(
-        net,
-        list(cfg.patch_shape),
-        in_channels=1,
-        time_distribution="uniform",
-        trajectory="linear",
-        odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}},
-        shape=list(cfg.shape),
-    )
+    common = dict(in_channels=1, time_distribution="uniform", trajectory="linear",
+                  odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=list(cfg.shape))
+    list_shape = [list(s) for s, _ in cfg.segments]
+    list_edges = [int(np.prod(s)) for s, _ in cfg.segments]
+    list_patch = [list(p) for _, p in cfg.segments]
+    if kind == "calochallenge":
+        model = CaloChallengeCFM(net, list(cfg.patch_shape), **common)
+    elif kind == "ds1":  # experiments/calochallenge/calochallenge_cfm/model.py:97
+        from experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM_DS1
+
+        assert all(p == list_patch[0] for p in list_patch)
+        model = CaloChallengeCFM_DS1(net, list_shape, list_edges, list_patch[0], **common)
+    elif kind == "calogan":  # experiments/calogan/model.py:8
+        from experiments.calogan.model import CaloGANCFM
+
+        model = CaloGANCFM(net, list_shape, list_edges, list_patch, **common)
+    elif kind == "calohad":  # experiments/calohadronic/model.py:8
+        from experiments.calohadronic.model import CaloHadCFM
+
+        model = CaloHadCFM(net, list_shape, list_edges, list_patch, **common)
+    elif kind == "lemurs":  # experiments/lemurs/model.py:8
+        from experiments.lemurs.model import LEMURSCFM
+
+        model = LEMURSCFM(net, list(cfg.patch_shape), **common)
+    else:
+        raise ValueError(kind)
     model.device = torch.device("cpu")
     model.dtype = torch.float32
     return model
@@ -143,9 +159,9 @@ def grad_probe(g: torch.Tensor, n=48):
     return idx, f[idx].numpy()
 
 
-def make_case(name, cfg, B, seed, sample_specs, train_steps):
+def make_case(name, cfg, B, seed, sample_specs, train_steps, kind="calochallenge"):
     torch.manual_seed(1234)
-    model = build_reference(cfg)
+    model = build_reference(cfg, kind=kind)
     # param inventory check against the oracle's list (names, shapes, order)
     ref_names = [k[4:] for k, _ in model.named_parameters()]
     assert ref_names == list(O.param_shapes(cfg).keys()), "state-dict order/name mismatch"
@@ -159,10 +175,16 @@ def make_case(name, cfg, B, seed, sample_specs, train_steps):
     # --- _batch_loss through the reference's own code path (models/base_model.py:203-218).
     # It draws t then x0 from the global CPU generator; re-seeding reproduces both.
     torch.manual_seed(seed + 100)
-    loss = model._batch_loss([x, c])
+    if kind == "lemurs":  # LEMURSCFM._batch_loss takes the dataset layout (B, R, A, L) and reorders it itself (lemurs/model.py:62-65)
+        loss = model._batch_loss([x[:, 0].permute(0, 3, 2, 1).contiguous(), c])
+    else:
+        loss = model._batch_loss([x.clone(), c])
     torch.manual_seed(seed + 100)
-    t = torch.rand([B, 1, 1, 1, 1])
-    x0 = torch.randn_like(x)
+    t = torch.rand([B] + [1] * (x.dim() - 1))
+    if kind == "lemurs":  # randn_like of the permuted VIEW fills in that view's memory order
+        x0 = torch.randn_like(x[:, 0].permute(0, 3, 2, 1).contiguous().permute(0, 3, 2, 1).unsqueeze(1)).contiguous()
+    else:
+        x0 = torch.randn_like(x)
     with torch.no_grad():
         x_t = (1 - t) * x0 + t * x
         v = model.forward(x_t, t.view(-1, 1), c)
@@ -263,6 +285,12 @@ def main():
     make_case("ds2_d2_b2", O.ds2(2), 2, 11, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)], 5)
     make_case("ds2_d6_b2", O.ds2(6), 2, 12, [("rk4_coarse", "rk4", 0.25)], 3)
     make_case("ds3_d6_b1", O.ds3(6), 1, 13, [("rk4_coarse", "rk4", 0.5)], 0)
+    # the other ViT-CFM geometries: multi-segment patching + position buffers
+    make_case("ds1_photons_d2_b3", O.ds1_photons(2), 3, 21, [("rk4_coarse", "rk4", 0.25)], 3, kind="ds1")
+    make_case("ds1_pions_d2_b2", O.ds1_pions(2), 2, 22, [("heun", "heun2", 0.25)], 0, kind="ds1")
+    make_case("calogan_d2_b3", O.calogan(2), 3, 23, [("rk4_coarse", "rk4", 0.25)], 3, kind="calogan")
+    make_case("calohad_d2_b1", O.calohad(2), 1, 24, [("rk4_coarse", "rk4", 0.5)], 2, kind="calohad")
+    make_case("lemurs_d2_b2", O.lemurs(2), 2, 25, [("rk4_coarse", "rk4", 0.25)], 0, kind="lemurs")
 
 
 if __name__ == "__main__":

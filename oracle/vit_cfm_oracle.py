@@ -38,19 +38,30 @@ class ViTConfig:
     num_heads: int = 6
     mlp_ratio: float = 4.0
     freq_dim: int = 256  # TimestepEmbedder frequency_embedding_size  nn/vit.py:359
+    # Multi-segment geometries (CaloChallengeCFM_DS1, CaloGANCFM, CaloHadCFM): a tuple of ((L, A, R), (p1, p2, p3)) per
+    # segment; `shape` is then (n_voxels,) (the flat sample of the YAML, e.g. cfm_ds1_photons.yaml:3) and `patch_shape` unused.
+    segments: tuple = ()
 
     @property
     def num_patches(self):
+        if self.segments:
+            raise ValueError("multi-segment geometry: use seg_num_patches")
         return tuple(s // p for s, p in zip(self.shape, self.patch_shape))
 
     @property
+    def seg_num_patches(self):
+        """[(l, a, r), ...] = the reference's num_patches_per_dim (e.g. calohadronic/model.py:36-46)"""
+        if not self.segments:
+            return [self.num_patches]
+        return [tuple(s // p for s, p in zip(shape, patch)) for shape, patch in self.segments]
+
+    @property
     def T(self):
-        l, a, r = self.num_patches
-        return l * a * r
+        return sum(l * a * r for l, a, r in self.seg_num_patches)
 
     @property
     def P(self):
-        p1, p2, p3 = self.patch_shape
+        p1, p2, p3 = self.segments[0][1] if self.segments else self.patch_shape
         return p1 * p2 * p3 * self.in_channels
 
     @property
@@ -68,6 +79,38 @@ def ds2(depth=6):
 
 def ds3(depth=6):
     return ViTConfig(shape=(45, 50, 18), patch_shape=(3, 10, 3), depth=depth)
+
+
+def _segmented(list_shape, list_patch_shape, condition_dim, depth):
+    segs = tuple((tuple(s), tuple(p)) for s, p in zip(list_shape, list_patch_shape))
+    return ViTConfig(shape=(sum(math.prod(s) for s in list_shape),), patch_shape=(), condition_dim=condition_dim, depth=depth, segments=segs)
+
+
+def ds1_photons(depth=6):
+    """configs/model/cfm/cfm_ds1_photons.yaml: 5 layers, 440 voxels -> 88 tokens of 5"""
+    shapes = [(1, 8, 5), (1, 16, 10), (1, 19, 10), (1, 5, 5), (1, 5, 5)]
+    return _segmented(shapes, [(1, 1, 5)] * 5, 6, depth)
+
+
+def ds1_pions(depth=6):
+    """configs/model/cfm/cfm_ds1_pions.yaml: 7 layers, 625 voxels -> 125 tokens of 5"""
+    shapes = [(1, 8, 5), (1, 10, 10), (1, 10, 10), (1, 5, 5), (1, 15, 10), (1, 16, 10), (1, 10, 5)]
+    return _segmented(shapes, [(1, 1, 5)] * 7, 8, depth)
+
+
+def calogan(depth=6):
+    """configs/model/cfm_calogan/cfm_eplus.yaml: 3 layers, 504 voxels -> 84 tokens of 6"""
+    return _segmented([(1, 96, 3), (1, 12, 12), (1, 6, 12)], [(1, 6, 1), (1, 2, 3), (1, 2, 3)], 4, depth)
+
+
+def calohad(depth=6):
+    """configs/model/cfm_calohad/cfm_calohad.yaml: ECal + HCal, 45450 voxels -> 606 tokens of 75"""
+    return _segmented([(10, 15, 15), (48, 30, 30)], [(5, 5, 3), (3, 5, 5)], 59, depth)
+
+
+def lemurs(depth=6):
+    """configs/model/cfm_lemurs/cfm_lemurs.yaml: the ds2 grid with 53 conditions"""
+    return ViTConfig(condition_dim=53, depth=depth)
 
 
 # --------------------------------------------------------------------------------------
@@ -171,25 +214,51 @@ def reference_init(cfg: ViTConfig, generator: torch.Generator, dtype=torch.float
 # --------------------------------------------------------------------------------------
 
 
-def to_patches(x, cfg: ViTConfig):
-    """(B, C, L*p1, A*p2, R*p3) -> (B, l*a*r, p1*p2*p3*C)   model.py:54-60"""
+def _to_patches_grid(x, num_patches, patch_shape):
     B, C = x.shape[0], x.shape[1]
-    l, a, r = cfg.num_patches
-    p1, p2, p3 = cfg.patch_shape
+    l, a, r = num_patches
+    p1, p2, p3 = patch_shape
     x = x.reshape(B, C, l, p1, a, p2, r, p3)
     x = x.permute(0, 2, 4, 6, 3, 5, 7, 1)  # b l a r p1 p2 p3 c
     return x.reshape(B, l * a * r, p1 * p2 * p3 * C)
 
 
-def from_patches(z, cfg: ViTConfig):
-    """(B, l*a*r, p1*p2*p3*C) -> (B, C, L, A, R)   model.py:40-52"""
+def _from_patches_grid(z, num_patches, patch_shape, C):
     B = z.shape[0]
-    C = cfg.in_channels
-    l, a, r = cfg.num_patches
-    p1, p2, p3 = cfg.patch_shape
+    l, a, r = num_patches
+    p1, p2, p3 = patch_shape
     z = z.reshape(B, l, a, r, p1, p2, p3, C)
     z = z.permute(0, 7, 1, 4, 2, 5, 3, 6)  # b c l p1 a p2 r p3
     return z.reshape(B, C, l * p1, a * p2, r * p3)
+
+
+def to_patches(x, cfg: ViTConfig):
+    """(B, C, L*p1, A*p2, R*p3) -> (B, l*a*r, p1*p2*p3*C)   model.py:54-60.
+    Multi-segment: (B, C, n_voxels) split at the segment edges, each piece patched on its own grid, tokens concatenated
+    (model.py:163-173, calogan/model.py:77-87, calohadronic/model.py:76-86)."""
+    if not cfg.segments:
+        return _to_patches_grid(x, cfg.num_patches, cfg.patch_shape)
+    B, C = x.shape[0], x.shape[1]
+    toks, off = [], 0
+    for (shape, patch), n in zip(cfg.segments, cfg.seg_num_patches):
+        v = math.prod(shape)
+        toks.append(_to_patches_grid(x[:, :, off : off + v].reshape(B, C, *shape), n, patch))
+        off += v
+    return torch.cat(toks, dim=1)
+
+
+def from_patches(z, cfg: ViTConfig):
+    """(B, l*a*r, p1*p2*p3*C) -> (B, C, L, A, R)   model.py:40-52; multi-segment: the inverse of the above, flat (B, C, n_voxels)
+    (model.py:146-161)."""
+    C = cfg.in_channels
+    if not cfg.segments:
+        return _from_patches_grid(z, cfg.num_patches, cfg.patch_shape, C)
+    pieces, off = [], 0
+    for (shape, patch), n in zip(cfg.segments, cfg.seg_num_patches):
+        t = n[0] * n[1] * n[2]
+        pieces.append(_from_patches_grid(z[:, off : off + t], n, patch, C).flatten(start_dim=2))
+        off += t
+    return torch.cat(pieces, dim=2)
 
 
 # --------------------------------------------------------------------------------------
@@ -198,13 +267,17 @@ def from_patches(z, cfg: ViTConfig):
 
 
 def meshgrid_buffers(cfg: ViTConfig, dtype=torch.float32):
-    """pos_z, pos_y, pos_x for the single-segment num_patches [[l, a, r]]   nn/vit.py:137-154"""
-    l, a, r = cfg.num_patches
-    lg = torch.arange(l) / l
-    ag = torch.arange(a) / a
-    rg = torch.arange(r) / r
-    z, y, x = torch.meshgrid(lg, ag, rg, indexing="ij")
-    return z.flatten().to(dtype), y.flatten().to(dtype), x.flatten().to(dtype)
+    """pos_z, pos_y, pos_x   nn/vit.py:137-154: the layer coordinate runs over ALL segments (arange(sum_l) / sum_l, sliced per
+    segment), the angular / radial coordinates restart in every segment."""
+    segs = cfg.seg_num_patches
+    sum_l = sum(n[0] for n in segs)
+    sum_lgrid = torch.arange(sum_l) / sum_l
+    zs, ys, xs, l0 = [], [], [], 0
+    for l, a, r in segs:
+        z, y, x = torch.meshgrid(sum_lgrid[l0 : l0 + l], torch.arange(a) / a, torch.arange(r) / r, indexing="ij")
+        zs.append(z.flatten()); ys.append(y.flatten()); xs.append(x.flatten())
+        l0 += l
+    return torch.cat(zs).to(dtype), torch.cat(ys).to(dtype), torch.cat(xs).to(dtype)
 
 
 def pos_embedding(freqs, cfg: ViTConfig):
@@ -299,7 +372,7 @@ def cfm_forward(p, x, t, c, cfg: ViTConfig):
 
 def cfm_loss(p, x1, c, t, x0, cfg: ViTConfig):
     """CFM._batch_loss with t and x0 injected   models/base_model.py:203-218,
-    linear_trajectory models/trajectories.py:5-8.  t is (B,1,1,1,1)."""
+    linear_trajectory models/trajectories.py:5-8.  t is (B,1,1,1,1) ((B,1,1) for the flat multi-segment samples)."""
     x_t = (1 - t) * x0 + t * x1
     x_t_dot = x1 - x0
     v = cfm_forward(p, x_t, t.view(-1, 1), c, cfg)
@@ -442,6 +515,6 @@ def synthetic_batch(cfg: ViTConfig, B: int, seed: int = 0, dtype=torch.float32):
 
 
 def synthetic_noise(cfg: ViTConfig, B: int, g: torch.Generator, dtype=torch.float32):
-    t = torch.rand((B, 1, 1, 1, 1), generator=g, dtype=dtype)
+    t = torch.rand((B, 1) + (1,) * len(cfg.shape), generator=g, dtype=dtype)  # broadcastable against (B, C, *shape)
     x0 = torch.randn((B, cfg.in_channels, *cfg.shape), generator=g, dtype=dtype)
     return t, x0

@@ -65,15 +65,44 @@ def ref_attention(qkv, B, T, H, dh):
     return (a @ v).transpose(1, 2).reshape(B * T, H * dh)
 
 
-def build_models(cfg, mode, fill, device=DEV):
-    """vit4hep_amd CaloChallengeCFM with the oracle's deterministic parameters loaded."""
-    from vit4hep_amd import CaloChallengeCFM, ViT
+def build_net(cfg, mode):
+    from vit4hep_amd import ViT
 
-    l, a, r = cfg.num_patches
-    net = ViT({"dim": 3, "condition_dim": cfg.condition_dim, "hidden_dim": cfg.hidden_dim, "depth": cfg.depth, "num_heads": cfg.num_heads,
-               "mlp_ratio": cfg.mlp_ratio, "patch_dim": cfg.P, "num_patches": [[l, a, r]], "learn_pos_embed": True, "amd_mode": mode,
-               "use_torch_sdpa": False, "pos_embedding_coords": "cylindrical"})
-    model = CaloChallengeCFM(net, list(cfg.patch_shape), in_channels=1, odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=list(cfg.shape))
+    return ViT({"dim": 3, "condition_dim": cfg.condition_dim, "hidden_dim": cfg.hidden_dim, "depth": cfg.depth, "num_heads": cfg.num_heads,
+                "mlp_ratio": cfg.mlp_ratio, "patch_dim": cfg.P, "num_patches": [list(n) for n in cfg.seg_num_patches], "learn_pos_embed": True,
+                "amd_mode": mode, "use_torch_sdpa": False, "pos_embedding_coords": "cylindrical"})
+
+
+def build_models(cfg, mode, fill, device=DEV, kind="calochallenge"):
+    """vit4hep_amd CFM wrapper (`kind`: calochallenge | ds1 | calogan | calohad | lemurs, the reference's wrapper classes) with the
+    oracle's deterministic parameters loaded."""
+    from vit4hep_amd import CaloChallengeCFM
+
+    net = build_net(cfg, mode)
+    common = dict(in_channels=1, odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=list(cfg.shape))
+    list_shape = [list(s) for s, _ in cfg.segments]
+    list_edges = [int(np.prod(s)) for s, _ in cfg.segments]
+    list_patch = [list(p) for _, p in cfg.segments]
+    if kind == "calochallenge":
+        model = CaloChallengeCFM(net, list(cfg.patch_shape), **common)
+    elif kind == "ds1":
+        from vit4hep_amd.experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM_DS1
+
+        model = CaloChallengeCFM_DS1(net, list_shape, list_edges, list_patch[0], **common)
+    elif kind == "calogan":
+        from vit4hep_amd.experiments.calogan.model import CaloGANCFM
+
+        model = CaloGANCFM(net, list_shape, list_edges, list_patch, **common)
+    elif kind == "calohad":
+        from vit4hep_amd.experiments.calohadronic.model import CaloHadCFM
+
+        model = CaloHadCFM(net, list_shape, list_edges, list_patch, **common)
+    elif kind == "lemurs":
+        from vit4hep_amd.experiments.lemurs.model import LEMURSCFM
+
+        model = LEMURSCFM(net, list(cfg.patch_shape), **common)
+    else:
+        raise ValueError(kind)
     sd = model.state_dict()
     for k, v in fill.items():
         assert sd["net." + k].shape == v.shape, k

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.load().v4h_abi_version() == 1
+    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_plan_inventory_matches_reference_state_dict():
@@ -39,6 +39,59 @@ def test_plan_inventory_matches_reference_state_dict():
         assert plan.num_stages == cfg.depth + 2
         assert plan.workspace_bytes(128, True) > plan.workspace_bytes(128, False) > 0
         assert plan.workspace_bytes(256, True) > plan.workspace_bytes(128, True)
+
+
+def test_mapped_plan_inventory_for_the_multisegment_geometries():
+    for cfg in (O.ds1_photons(6), O.ds1_pions(6), O.calogan(6), O.calohad(6)):
+        plan = _lib.Plan(None, None, cfg.condition_dim, cfg.hidden_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden, mapped=(cfg.T, cfg.P, cfg.shape[0]))
+        assert plan.mapped and plan.shapes == [tuple(s) for s in O.param_shapes(cfg).values()]
+        assert plan.workspace_bytes(64, True) > plan.workspace_bytes(64, False) > 0
+    with pytest.raises(RuntimeError, match="must be positive"):
+        _lib.Plan(None, None, 6, 480, 2, 6, 1920, mapped=(0, 5, 440))
+    with pytest.raises(RuntimeError, match="int32"):
+        _lib.Plan(None, None, 6, 480, 2, 6, 1920, mapped=(88, 5, 1 << 31))
+
+
+def test_segment_patch_map_is_the_reference_permutation():
+    """The index table = what split / rearrange / cat does to voxel indices (oracle restatement of calochallenge_cfm/model.py:163-173)."""
+    from vit4hep_amd.patching import multi_segment_meshgrid, segment_patch_map
+
+    for cfg in (O.ds1_photons(1), O.ds1_pions(1), O.calogan(1), O.calohad(1)):
+        shapes, patches = [s for s, _ in cfg.segments], [p for _, p in cfg.segments]
+        pm, per_dim, per_layer, V = segment_patch_map(shapes, [math.prod(s) for s in shapes], patches)
+        assert V == cfg.shape[0] and pm.shape == (cfg.T, cfg.P) and pm.dtype == np.int32
+        assert per_dim == cfg.seg_num_patches and sum(per_layer) == cfg.T
+        want = O.to_patches(torch.arange(V, dtype=torch.float32).reshape(1, 1, V), cfg)[0].numpy()
+        assert np.array_equal(pm, want.astype(np.int32))
+        assert np.array_equal(np.sort(pm.ravel()), np.arange(V))  # a permutation: every voxel exactly once
+        for got, ref in zip(multi_segment_meshgrid(cfg.seg_num_patches), O.meshgrid_buffers(cfg)):
+            assert np.array_equal(got, ref.numpy())
+    with pytest.raises(AssertionError, match=r"Input size \(19\) should be divisible by patch size \(2\) in axis 2"):
+        segment_patch_map([(1, 8, 5), (1, 16, 10), (1, 19, 10)], [40, 160, 190], [(1, 2, 5)] * 3)
+    with pytest.raises(ValueError, match="list_edges"):
+        segment_patch_map([(1, 8, 5)], [41], [(1, 1, 5)])
+    with pytest.raises(ValueError, match="same patch_dim"):
+        segment_patch_map([(1, 8, 5), (1, 8, 4)], [40, 32], [(1, 1, 5), (1, 1, 4)])
+
+
+def test_multisegment_wrappers_mirror_the_reference_constructors():
+    from tests import hiputil as U
+
+    for cfg, kind, cls in ((O.ds1_photons(1), "ds1", "CaloChallengeCFM_DS1"), (O.calogan(1), "calogan", "CaloGANCFM"), (O.calohad(1), "calohad", "CaloHadCFM"),
+                           (O.lemurs(1), "lemurs", "LEMURSCFM")):
+        m = U.build_models(cfg, "f32", O.golden_fill(cfg), device="cpu", kind=kind)
+        assert type(m).__name__ == cls and m.in_channels == 1 and m.shape == list(cfg.shape)
+        core = m._core()
+        assert core.num_tokens == cfg.T and core.voxel_shape() == tuple(cfg.shape)
+        if cfg.segments:
+            assert m.list_edges == [math.prod(s) for s, _ in cfg.segments] and m.num_patches_per_layer == [l * a * r for l, a, r in cfg.seg_num_patches]
+            assert [tuple(n) for n in core.num_patches] == cfg.seg_num_patches and not core.map_has_holes()
+            assert core._get_plan().mapped
+        with pytest.raises(RuntimeError, match="MI355X"):  # still no CPU path
+            m.forward(torch.zeros((1, 1, *cfg.shape)), torch.zeros(1, 1), torch.zeros(1, cfg.condition_dim))
+    from vit4hep_amd.experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM, CaloChallengeCFM_DS1
+
+    assert issubclass(CaloChallengeCFM_DS1, CaloChallengeCFM)  # as in the reference (model.py:97)
 
 
 def test_plan_rejects_what_the_reference_asserts():
@@ -101,7 +154,7 @@ def test_unsupported_options_fail_loudly():
     from vit4hep_amd import ViT
 
     base = {"hidden_dim": 480, "depth": 1, "num_heads": 6, "mlp_ratio": 4, "patch_dim": 48, "num_patches": [[15, 1, 9]]}
-    for bad in ({"learn_pos_embed": False}, {"causal_attn": True}, {"attn_drop": 0.1}, {"num_patches": [[5, 1, 9], [10, 1, 9]]}):
+    for bad in ({"learn_pos_embed": False}, {"causal_attn": True}, {"attn_drop": 0.1}, {"num_patches": [[5, 9], [10, 9]]}, {"dim": 2}):
         with pytest.raises(NotImplementedError):
             ViT({**base, **bad})
     with pytest.raises(ValueError):
@@ -151,6 +204,9 @@ def test_dropin_aliases_reference_module_paths():
         mod = importlib.import_module("experiments.calochallenge.calochallenge_cfm.model")
         assert mod.CaloChallengeCFM.__module__.startswith("vit4hep_amd")
         assert importlib.import_module("models.base_model").CFM.__module__.startswith("vit4hep_amd")
+        assert mod.CaloChallengeCFM_DS1.__module__.startswith("vit4hep_amd")  # configs/model/cfm/cfm_ds1_photons.yaml:1
+        for path, cls in (("experiments.calogan.model", "CaloGANCFM"), ("experiments.calohadronic.model", "CaloHadCFM"), ("experiments.lemurs.model", "LEMURSCFM")):
+            assert getattr(importlib.import_module(path), cls).__module__.startswith("vit4hep_amd")  # configs/model/cfm_{calogan,calohad,lemurs}/*.yaml:1
     finally:
         dropin.uninstall()
         for k, v in saved.items():

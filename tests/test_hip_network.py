@@ -144,8 +144,14 @@ def test_update_step_trajectory_vs_golden(name, golden):
         assert abs(loss.item() - g["train/losses"][k]) / g["train/losses"][k] < 1e-4, (k, loss.item())
         assert abs(gn.item() - g["train/gnorms"][k]) / g["train/gnorms"][k] < 1e-3, k
     sd = model.state_dict()
+    D = cfg.hidden_dim
     for k in ("pos_embed_freqs", "blocks.0.attn.qkv.bias", "final_layer.linear.bias"):
-        assert U.rel_err(sd["net." + k], torch.from_numpy(g["train/final/" + k])) < 1e-4, k
+        got, want = sd["net." + k].cpu(), torch.from_numpy(g["train/final/" + k])
+        if k.endswith("qkv.bias"):  # key-bias gradient is analytically zero (softmax shift invariance): Adam-normalised noise, bounded not compared
+            assert (got[D : 2 * D] - want[D : 2 * D]).abs().max() <= 2 * 1e-4 * len(g["train/losses"])
+            keep = torch.cat([torch.arange(0, D), torch.arange(2 * D, 3 * D)])
+            got, want = got[keep], want[keep]
+        assert U.rel_err(got, want) < 1e-4, k
 
 
 def test_torch_optimizer_dropin_matches_native_trainer(golden):

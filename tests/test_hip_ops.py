@@ -134,10 +134,10 @@ def test_patchify_bit_exact(cfg):
     x = torch.randn((3, 1, *cfg.shape), generator=torch.Generator().manual_seed(0))
     xd = x.to(U.DEV)
     tok = torch.empty((3, cfg.T, cfg.P), device=U.DEV)
-    _lib.check(_lib.load().v4h_op_patchify(plan.handle, _lib.ptr(xd), _lib.ptr(tok), 3, _lib.stream_ptr()))
+    _lib.check(_lib.load().v4h_op_patchify(plan.handle, _lib.ptr(xd), _lib.ptr(tok), 3, _lib.stream_ptr(), None))
     assert torch.equal(tok.cpu(), O.to_patches(x, cfg))
     back = torch.empty_like(xd)
-    _lib.check(_lib.load().v4h_op_unpatchify(plan.handle, _lib.ptr(tok), _lib.ptr(back), 3, _lib.stream_ptr()))
+    _lib.check(_lib.load().v4h_op_unpatchify(plan.handle, _lib.ptr(tok), _lib.ptr(back), 3, _lib.stream_ptr(), None))
     assert torch.equal(back.cpu(), x)
     assert torch.equal(back.cpu(), O.from_patches(O.to_patches(x, cfg), cfg))
 
@@ -150,7 +150,7 @@ def test_pos_embedding_vs_golden(name, cfg, golden):
     plan = _lib.Plan(cfg.shape, cfg.patch_shape, 46, 480, cfg.depth, 6, 1920)
     freqs = O.golden_fill(cfg)["pos_embed_freqs"].to(U.DEV)
     pe = torch.empty((cfg.T, 480), device=U.DEV)
-    _lib.check(_lib.load().v4h_op_pos_embed(plan.handle, _lib.ptr(freqs), _lib.ptr(pe), _lib.stream_ptr()))
+    _lib.check(_lib.load().v4h_op_pos_embed(plan.handle, _lib.ptr(freqs), _lib.ptr(pe), _lib.stream_ptr(), None))
     assert float((pe.cpu().double() - torch.from_numpy(g["pos_embed"]).double()).abs().max()) < 2e-6
 
 

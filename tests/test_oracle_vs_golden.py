@@ -7,7 +7,14 @@ import torch
 
 from oracle import vit_cfm_oracle as O
 
-CASES = {"ds2_d2_b2": O.ds2(2), "ds2_d6_b2": O.ds2(6), "ds3_d6_b1": O.ds3(6)}
+CASES = {"ds2_d2_b2": O.ds2(2), "ds2_d6_b2": O.ds2(6), "ds3_d6_b1": O.ds3(6),
+         # the other ViT-CFM geometries: multi-segment patching (DS1 / CaloGAN / CaloHad wrappers of the reference), LEMURS
+         "ds1_photons_d2_b3": O.ds1_photons(2), "ds1_pions_d2_b2": O.ds1_pions(2), "calogan_d2_b3": O.calogan(2),
+         "calohad_d2_b1": O.calohad(2), "lemurs_d2_b2": O.lemurs(2)}
+SEEDS = {"ds2_d2_b2": 11, "ds2_d6_b2": 12, "ds3_d6_b1": 13, "ds1_photons_d2_b3": 21, "ds1_pions_d2_b2": 22, "calogan_d2_b3": 23,
+         "calohad_d2_b1": 24, "lemurs_d2_b2": 25}
+NPARAMS = {"ds2_d2_b2": 9424928, "ds2_d6_b2": 26042528, "ds3_d6_b1": 26082890, "ds1_photons_d2_b3": 9364405, "ds1_pions_d2_b2": 9365365,
+           "calogan_d2_b3": 9364406, "calohad_d2_b1": 9457115, "lemurs_d2_b2": 9428288}
 RTOL = 2e-5  # fp32 CPU vs fp32 CPU, different op order only
 
 
@@ -23,7 +30,7 @@ def test_param_inventory(name, golden):
     cfg = CASES[name]
     n = sum(int(np.prod(s)) for s in O.param_shapes(cfg).values())
     assert n == int(g["nparams"])
-    assert n == {"ds2_d2_b2": 9424928, "ds2_d6_b2": 26042528, "ds3_d6_b1": 26082890}[name]
+    assert n == NPARAMS[name]
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -33,7 +40,7 @@ def test_forward_loss_grads(name, golden):
     p = O.golden_fill(cfg)
     x, c, t, x0 = (torch.from_numpy(g[k]) for k in ("x", "c", "t", "x0"))
     # the synthetic generator is part of the contract too
-    seed = {"ds2_d2_b2": 11, "ds2_d6_b2": 12, "ds3_d6_b1": 13}[name]
+    seed = SEEDS[name]
     xs, cs, _ = O.synthetic_batch(cfg, x.shape[0], seed)
     assert torch.equal(xs, x) and torch.equal(cs, c)
 
@@ -58,7 +65,10 @@ def test_forward_loss_grads(name, golden):
 
 
 @pytest.mark.parametrize("name,tag,method", [("ds2_d2_b2", "rk4", "rk4"), ("ds2_d2_b2", "heun", "heun2"),
-                                             ("ds2_d6_b2", "rk4_coarse", "rk4"), ("ds3_d6_b1", "rk4_coarse", "rk4")])
+                                             ("ds2_d6_b2", "rk4_coarse", "rk4"), ("ds3_d6_b1", "rk4_coarse", "rk4"),
+                                             ("ds1_photons_d2_b3", "rk4_coarse", "rk4"), ("ds1_pions_d2_b2", "heun", "heun2"),
+                                             ("calogan_d2_b3", "rk4_coarse", "rk4"), ("calohad_d2_b1", "rk4_coarse", "rk4"),
+                                             ("lemurs_d2_b2", "rk4_coarse", "rk4")])
 def test_sampler(name, tag, method, golden):
     g = golden(name)
     cfg = CASES[name]
@@ -73,7 +83,7 @@ def test_fixed_grid():
     assert len(O.fixed_grid(0.0, 1.0, 0.25)) == 5
 
 
-@pytest.mark.parametrize("name", ["ds2_d2_b2", "ds2_d6_b2"])
+@pytest.mark.parametrize("name", ["ds2_d2_b2", "ds2_d6_b2", "ds1_photons_d2_b3", "calogan_d2_b3", "calohad_d2_b1"])
 def test_update_step_trajectory(name, golden):
     """AdamW + clip + cosine LR as in BaseExperiment._step (base_experiment.py:555-597)."""
     g = golden(name)
@@ -85,8 +95,16 @@ def test_update_step_trajectory(name, golden):
         loss, gn = O.train_step(p, st, x, c, torch.from_numpy(g["train/t"][k]), torch.from_numpy(g["train/x0"][k]), cfg)
         assert abs(loss - g["train/losses"][k]) / g["train/losses"][k] < 1e-4, (k, loss)
         assert abs(gn - g["train/gnorms"][k]) / g["train/gnorms"][k] < 1e-3, (k, gn)
+    D = cfg.hidden_dim
     for k in ("pos_embed_freqs", "blocks.0.attn.qkv.bias", "final_layer.linear.bias"):
-        assert rel(p[k].numpy(), g["train/final/" + k]) < 1e-4, k
+        got, want = p[k].numpy(), g["train/final/" + k]
+        if k.endswith("qkv.bias"):
+            # softmax is invariant to a shift of all scores of a row, so d loss / d (key bias) is analytically ZERO: what both
+            # sides hold there is rounding noise, which Adam normalises to +-lr per step.  Bound it instead of comparing it.
+            steps = len(g["train/losses"])
+            assert np.abs(got[D : 2 * D] - want[D : 2 * D]).max() <= 2 * 1e-4 * steps
+            got, want = np.delete(got, np.s_[D : 2 * D]), np.delete(want, np.s_[D : 2 * D])
+        assert rel(got, want) < 1e-4, k
 
 
 def test_hash_fill_is_platform_independent():

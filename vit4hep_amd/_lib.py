@@ -14,6 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libvit4hep_hip.so")
 
+ABI_VERSION = 2
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -42,12 +43,13 @@ SIGNATURES = {
     "v4h_abi_version": (_i32, []),
     "v4h_last_error": (C.c_char_p, []),
     "v4h_plan_create": (_i32, [C.POINTER(V4HConfig), _pp]),
+    "v4h_plan_create_mapped": (_i32, [C.POINTER(V4HConfig), _i32, _i32, _i64, _pp]),
     "v4h_plan_destroy": (None, [_vp]),
     "v4h_plan_num_params": (_i32, [_vp]),
     "v4h_plan_param_shape": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "v4h_plan_workspace_bytes": (_sz, [_vp, _i32, _i32]),
-    "v4h_vit_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
-    "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp]),
+    "v4h_vit_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),
+    "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),
     "v4h_cfm_prepare": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
@@ -59,9 +61,9 @@ SIGNATURES = {
     "v4h_op_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "v4h_op_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "v4h_op_ln_modulate_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "v4h_op_patchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
-    "v4h_op_unpatchify": (_i32, [_vp, _vp, _vp, _i32, _vp]),
-    "v4h_op_pos_embed": (_i32, [_vp, _vp, _vp, _vp]),
+    "v4h_op_patchify": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "v4h_op_unpatchify": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "v4h_op_pos_embed": (_i32, [_vp, _vp, _vp, _vp, _vp]),
     "v4h_debug_set_gemm_cfg": (None, [_i32, _i32]),
 }
 
@@ -86,8 +88,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.v4h_abi_version() != 1:
-        raise RuntimeError(f"libvit4hep_hip.so ABI {lib.v4h_abi_version()} != 1")
+    if lib.v4h_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libvit4hep_hip.so ABI {lib.v4h_abi_version()} != {ABI_VERSION}: rebuild with `python -m vit4hep_amd.build`")
     _lib = lib
     return lib
 
@@ -146,13 +148,16 @@ def pointer_table(tensors):
 
 
 class Plan:
-    """Host-side plan (sizes + workspace layout) for one (geometry, network, mode)."""
+    """Host-side plan (sizes + workspace layout) for one (geometry, network, mode).
 
-    def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1):
+    Regular grid: ``shape`` / ``patch_shape``.  General geometry: ``mapped=(tokens, patch_dim, voxels)`` (shape / patch_shape
+    ignored); forward / backward calls then need the index map and position table (include/vit4hep_hip.h)."""
+
+    def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1, mapped=None):
         lib = load()
         cfg = V4HConfig()
-        cfg.shape[:] = [int(v) for v in shape]
-        cfg.patch_shape[:] = [int(v) for v in patch_shape]
+        cfg.shape[:] = [int(v) for v in (shape if mapped is None else (0, 0, 0))]
+        cfg.patch_shape[:] = [int(v) for v in (patch_shape if mapped is None else (0, 0, 0))]
         cfg.in_channels = int(in_channels)
         cfg.condition_dim = int(condition_dim)
         cfg.hidden_dim = int(hidden_dim)
@@ -164,7 +169,12 @@ class Plan:
         self.mode = cfg.mode
         self.cfg = cfg
         h = C.c_void_p()
-        check(lib.v4h_plan_create(C.byref(cfg), C.byref(h)), "v4h_plan_create")
+        self.mapped = mapped is not None
+        if mapped is None:
+            check(lib.v4h_plan_create(C.byref(cfg), C.byref(h)), "v4h_plan_create")
+        else:
+            tokens, patch_dim, voxels = (int(v) for v in mapped)
+            check(lib.v4h_plan_create_mapped(C.byref(cfg), tokens, patch_dim, voxels, C.byref(h)), "v4h_plan_create_mapped")
         self.handle = h
         self.num_params = lib.v4h_plan_num_params(h)
         self.num_stages = lib.v4h_vit_num_backward_stages(h)

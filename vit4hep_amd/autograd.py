@@ -10,23 +10,29 @@ from . import _lib
 
 
 def _vox_shape(net, B):
-    shape, _ = net.geometry()
-    return (B, 1, *shape)
+    return (B, 1, *net.voxel_shape())
 
 
 def _patchify(net, vox):
     plan = net._get_plan()
     B = vox.shape[0]
+    if tuple(vox.shape) != _vox_shape(net, B):
+        raise RuntimeError(f"to_patches: input shape {tuple(vox.shape)} does not match the geometry {_vox_shape(net, B)}")
+    pmap, _ = net.device_tables(vox.device)
     tok = torch.empty((B, net.num_tokens, int(net.patch_dim)), dtype=torch.float32, device=vox.device)
-    _lib.check(_lib.load().v4h_op_patchify(plan.handle, _lib.ptr(vox), _lib.ptr(tok), B, _lib.stream_ptr(vox.device)), "v4h_op_patchify")
+    _lib.check(_lib.load().v4h_op_patchify(plan.handle, _lib.ptr(vox), _lib.ptr(tok), B, _lib.stream_ptr(vox.device), _lib.ptr(pmap)), "v4h_op_patchify")
     return tok
 
 
 def _unpatchify(net, tok):
     plan = net._get_plan()
     B = tok.shape[0]
-    vox = torch.empty(_vox_shape(net, B), dtype=torch.float32, device=tok.device)
-    _lib.check(_lib.load().v4h_op_unpatchify(plan.handle, _lib.ptr(tok), _lib.ptr(vox), B, _lib.stream_ptr(tok.device)), "v4h_op_unpatchify")
+    if tuple(tok.shape) != (B, net.num_tokens, int(net.patch_dim)):
+        raise RuntimeError(f"from_patches: input shape {tuple(tok.shape)} does not match (B, {net.num_tokens}, {int(net.patch_dim)})")
+    pmap, _ = net.device_tables(tok.device)
+    # voxels no token maps to (index -1 never occurs for the reference's rearrange patterns) stay zero
+    vox = (torch.zeros if net.map_has_holes() else torch.empty)(_vox_shape(net, B), dtype=torch.float32, device=tok.device)
+    _lib.check(_lib.load().v4h_op_unpatchify(plan.handle, _lib.ptr(tok), _lib.ptr(vox), B, _lib.stream_ptr(tok.device), _lib.ptr(pmap)), "v4h_op_unpatchify")
     return vox
 
 
@@ -35,13 +41,16 @@ def run_forward(net, params, x_vox, t, c, training, ws=None):
     plan = net._get_plan()
     B = x_vox.shape[0]
     dev = x_vox.device
+    if tuple(x_vox.shape) != _vox_shape(net, B):  # the kernels index by the plan's geometry: never launch on a mismatching buffer
+        raise RuntimeError(f"input shape {tuple(x_vox.shape)} does not match the network geometry {_vox_shape(net, B)}")
     if ws is None:
         ws = torch.empty(plan.workspace_bytes(B, training), dtype=torch.uint8, device=dev) if training else net.inference_workspace(B, dev)
-    out = torch.empty_like(x_vox)
+    out = torch.zeros_like(x_vox) if net.map_has_holes() else torch.empty_like(x_vox)
     tab = _lib.pointer_table(params)
+    pmap, pos = net.device_tables(dev)
     _lib.check(
         _lib.load().v4h_vit_forward(plan.handle, B, tab, _lib.ptr(x_vox), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                    1 if training else 0, _lib.stream_ptr(dev)),
+                                    1 if training else 0, _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos)),
         "v4h_vit_forward",
     )
     return out, ws
@@ -52,9 +61,10 @@ def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=Non
     B = dout_vox.shape[0] if dout_vox is not None else None
     if stage_last is None:
         stage_last = plan.num_stages - 1
+    pmap, pos = net.device_tables(ws.device)
     _lib.check(
         _lib.load().v4h_vit_backward(plan.handle, B, _lib.pointer_table(params), _lib.pointer_table(grads), _lib.ptr(dout_vox), _lib.ptr(ws), ws.numel(),
-                                     stage_first, stage_last, _lib.stream_ptr(ws.device)),
+                                     stage_first, stage_last, _lib.stream_ptr(ws.device), _lib.ptr(pmap), _lib.ptr(pos)),
         "v4h_vit_backward",
     )
 
@@ -74,7 +84,7 @@ class _ViTFunction(torch.autograd.Function):
     def forward(ctx, net, x, t, c, patches_io, *params):
         x_vox = _unpatchify(net, x) if patches_io else x
         if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):
-            raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {net.geometry()}")
+            raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {_vox_shape(net, x_vox.shape[0])}")
         training = any(ctx.needs_input_grad[5:])
         detached = [p.detach() for p in params]
         out, ws = run_forward(net, detached, x_vox, t, c, training)
@@ -110,6 +120,6 @@ def vit_apply(net, x, t, c, patches_io):
         return _ViTFunction.apply(net, x, t, c, patches_io, *params)
     x_vox = _unpatchify(net, x) if patches_io else x
     if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):
-        raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {net.geometry()}")
+        raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {_vox_shape(net, x_vox.shape[0])}")
     out, _ = run_forward(net, [p.detach() for p in params], x_vox, t, c, False)
     return _patchify(net, out) if patches_io else out

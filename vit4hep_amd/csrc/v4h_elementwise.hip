@@ -77,6 +77,67 @@ __global__ void unpatchify_kernel(const float* __restrict__ tok, int ld, float* 
   vox[idx] = tok[((long)b * Tn + n) * ld + f];
 }
 
+// General geometry: gather / scatter through an index table (multi-segment patching of the DS1 / CaloGAN / CaloHad wrappers:
+// torch.split by list_edges + per-segment rearrange + cat, e.g. calochallenge_cfm/model.py:143-173).
+template <typename TO> __global__ void patchify_map_kernel(const float* __restrict__ vox, const int* __restrict__ map, TO* __restrict__ xp, int B, long V, int Tn, int P,
+                                                          int Ppad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)Tn * Ppad;
+  if (idx >= (long)B * per) return;
+  const int b = (int)(idx / per);
+  const int rem = (int)(idx % per), n = rem / Ppad, f = rem % Ppad;
+  float v = 0.f;
+  if (f < P) {
+    const int vi = map[(long)n * P + f];
+    if (vi >= 0) v = vox[(long)b * V + vi];
+  }
+  xp[idx] = (TO)v;
+}
+__global__ void unpatchify_map_kernel(const float* __restrict__ tok, int ld, const int* __restrict__ map, float* __restrict__ vox, int B, long V, int Tn, int P) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long per = (long)Tn * P;
+  if (idx >= (long)B * per) return;
+  const int b = (int)(idx / per);
+  const int rem = (int)(idx % per), n = rem / P, f = rem % P;
+  const int vi = map[rem];
+  if (vi >= 0) vox[(long)b * V + vi] = tok[((long)b * Tn + n) * ld + f];
+}
+// positional embedding from explicit position buffers pos = [pos_x | pos_y | pos_z] (T each)
+__global__ void pos_embed_fwd_pos_kernel(const float* __restrict__ freqs, const float* __restrict__ pos, float* __restrict__ pe, int Tn, int D) {
+  const int nf = D / 6;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Tn * 3 * nf) return;
+  const int n = idx / (3 * nf), rem = idx % (3 * nf), axis = rem / nf, j = rem % nf;
+  const float arg = pos[axis * Tn + n] * (freqs[j] * 6.283185307179586f);
+  pe[(long)n * D + axis * 2 * nf + j] = sinf(arg);
+  pe[(long)n * D + axis * 2 * nf + nf + j] = cosf(arg);
+}
+__global__ void pos_embed_bwd_pos_kernel(const float* __restrict__ G, const float* __restrict__ freqs, const float* __restrict__ pos, float* __restrict__ dfreqs, int Tn,
+                                         int D) {
+  const int nf = D / 6;
+  const int j = blockIdx.x;
+  const float w = freqs[j] * 6.283185307179586f;
+  float s = 0.f;
+  for (int n = threadIdx.x; n < Tn; n += blockDim.x) {
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+      const float ps = pos[axis * Tn + n];
+      const float arg = ps * w;
+      const float gs = G[(long)n * D + axis * 2 * nf + j], gc = G[(long)n * D + axis * 2 * nf + nf + j];
+      s += ps * (gs * cosf(arg) - gc * sinf(arg));
+    }
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) tot += red[w2];
+    atomicAdd(dfreqs + j, tot * 6.283185307179586f);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ embeddings
 // ViT.learnable_pos_embedding (nn/vit.py:156-162) with create_meshgrid buffers (nn/vit.py:137-154), single segment:
 // pe[n] = [sin(px w), cos(px w), sin(py w), cos(py w), sin(pz w), cos(pz w)], w = 2 pi freqs, each D/6 wide.
@@ -451,6 +512,36 @@ int unpatchify_f32(const float* tok, int ld, float* vox, int B, const PatchGeom&
   const long n = (long)B * g.L * g.A * g.R;
   hipLaunchKernelGGL(unpatchify_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, tok, ld, vox, B, g, P);
   V4H_CHECK_LAUNCH("unpatchify");
+  return V4H_OK;
+}
+int patchify_map(Mode m, bool out_f32, const float* vox, const int* map, void* xp, int B, long V, int T, int P, int Ppad, hipStream_t s) {
+  const long n = (long)B * T * Ppad;
+  const int nb = (int)((n + 255) / 256);
+  if (m == MODE_BF16 && !out_f32) hipLaunchKernelGGL(patchify_map_kernel<bf16>, dim3(nb), dim3(256), 0, s, vox, map, (bf16*)xp, B, V, T, P, Ppad);
+  else hipLaunchKernelGGL(patchify_map_kernel<float>, dim3(nb), dim3(256), 0, s, vox, map, (float*)xp, B, V, T, P, Ppad);
+  V4H_CHECK_LAUNCH("patchify_map");
+  return V4H_OK;
+}
+int unpatchify_map_f32(const float* tok, int ld, const int* map, float* vox, int B, long V, int T, int P, hipStream_t s) {
+  const long n = (long)B * T * P;
+  hipLaunchKernelGGL(unpatchify_map_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, tok, ld, map, vox, B, V, T, P);
+  V4H_CHECK_LAUNCH("unpatchify_map");
+  return V4H_OK;
+}
+int pos_embed_fwd_pos(const float* freqs, const float* pos, float* pe, int T, int D, hipStream_t s) {
+  V4H_CHECK_ARG(D % 6 == 0, "pos_embed: hidden_dim %d not divisible by 6", D);
+  const int n = T * 3 * (D / 6);
+  hipLaunchKernelGGL(pos_embed_fwd_pos_kernel, dim3((n + 255) / 256), dim3(256), 0, s, freqs, pos, pe, T, D);
+  V4H_CHECK_LAUNCH("pos_embed_fwd_pos");
+  return V4H_OK;
+}
+int pos_embed_bwd_pos(Mode m, const void* dx0, const float* freqs, const float* pos, float* dfreqs, float* scratch, int B, int T, int D, hipStream_t s) {
+  const int TD = T * D;
+  if (m == MODE_BF16) hipLaunchKernelGGL(sum_over_batch_kernel<bf16>, dim3((TD + 255) / 256), dim3(256), 0, s, (const bf16*)dx0, scratch, B, TD);
+  else hipLaunchKernelGGL(sum_over_batch_kernel<float>, dim3((TD + 255) / 256), dim3(256), 0, s, (const float*)dx0, scratch, B, TD);
+  V4H_CHECK_LAUNCH("pos_embed_bwd/sum");
+  hipLaunchKernelGGL(pos_embed_bwd_pos_kernel, dim3(D / 6), dim3(256), 0, s, scratch, freqs, pos, dfreqs, T, D);
+  V4H_CHECK_LAUNCH("pos_embed_bwd_pos");
   return V4H_OK;
 }
 int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipStream_t s) {

@@ -53,6 +53,7 @@ struct EpiArgs {
   const float* auxf; int ld_auxf;       // f32 auxiliary
   PatchGeom pg; int P;                  // EPI_UNPATCH: real patch_dim (columns >= P are padding)
   long slab_stride;                     // EPI_SLAB_F32: elements between the partial results of consecutive K splits
+  const int* map; long V;               // EPI_UNPATCH, mapped geometry: voxel index of (token n, feature f) = map[n*P + f] (or -1), V voxels per sample
 };
 
 struct GemmArgs {
@@ -174,6 +175,18 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       // token n = (li*a + ai)*r + ri ; feature f = (pi*p2 + pj)*p3 + pk  ->  voxel (li*p1+pi, ai*p2+pj, ri*p3+pk)
       const PatchGeom& g = e.pg;
       const int b = i / e.T, n = i % e.T;
+      if (e.map != nullptr) {  // general geometry: table lookup
+        float* ov = reinterpret_cast<float*>(e.out) + (size_t)b * e.V;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int f = j + r;
+          if (f < e.P) {
+            const int vi = e.map[(size_t)n * e.P + f];
+            if (vi >= 0) ov[vi] = v.v[r];
+          }
+        }
+        return;
+      }
       const int ri = n % g.r, ai = (n / g.r) % g.a, li = n / (g.r * g.a);
       float* op = reinterpret_cast<float*>(e.out) + (size_t)b * g.L * g.A * g.R;
 #pragma unroll

@@ -29,6 +29,11 @@ int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_
 
 int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s);
 int unpatchify_f32(const float* tok, int ld, float* vox, int B, const PatchGeom& g, int P, hipStream_t s);
+// general geometry (index map [T*P], V voxels per sample)
+int patchify_map(Mode m, bool out_f32, const float* vox, const int* map, void* xp, int B, long V, int T, int P, int Ppad, hipStream_t s);
+int unpatchify_map_f32(const float* tok, int ld, const int* map, float* vox, int B, long V, int T, int P, hipStream_t s);
+int pos_embed_fwd_pos(const float* freqs, const float* pos, float* pe, int T, int D, hipStream_t s);
+int pos_embed_bwd_pos(Mode m, const void* dx0, const float* freqs, const float* pos, float* dfreqs, float* scratch, int B, int T, int D, hipStream_t s);
 int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipStream_t s);
 int pos_embed_bwd(Mode m, const void* dx0, const float* freqs, float* dfreqs, float* scratch, int B, const PatchGeom& g, int D, hipStream_t s);
 int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t s);

@@ -34,6 +34,8 @@ struct v4h_plan {
   Mode mode;
   int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;
   PatchGeom pg;
+  bool mapped = false;  // general geometry: gather / scatter through a caller-provided index map, positions from a caller-provided table
+  long V = 0;           // voxels per sample
   std::vector<int> rows, cols;  // per parameter; cols == 0 for 1-D tensors
   int nparams() const { return (int)rows.size(); }
   int blk(int i, int k) const { return P_BLOCK0 + B_COUNT * i + k; }
@@ -76,13 +78,18 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int32_t v4h_abi_version(void) { return V4H_ABI_VERSION; }
 extern "C" const char* v4h_last_error(void) { return g_err; }
 
-extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) {
+static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int patch_dim, long voxels, v4h_plan** out) {
   V4H_CHECK_ARG(c && out, "plan_create: null argument");
   V4H_CHECK_ARG(c->mode == V4H_MODE_F32 || c->mode == V4H_MODE_BF16, "plan_create: unknown mode %d", c->mode);
   V4H_CHECK_ARG(c->in_channels == 1, "plan_create: in_channels %d unsupported (every shape-CFM config uses 1)", c->in_channels);
-  for (int k = 0; k < 3; ++k)
-    V4H_CHECK_ARG(c->shape[k] > 0 && c->patch_shape[k] > 0 && c->shape[k] % c->patch_shape[k] == 0,
-                  "Input size (%d) should be divisible by patch size (%d) in axis %d.", c->shape[k], c->patch_shape[k], k);
+  if (!mapped) {
+    for (int k = 0; k < 3; ++k)
+      V4H_CHECK_ARG(c->shape[k] > 0 && c->patch_shape[k] > 0 && c->shape[k] % c->patch_shape[k] == 0,
+                    "Input size (%d) should be divisible by patch size (%d) in axis %d.", c->shape[k], c->patch_shape[k], k);
+  } else {
+    V4H_CHECK_ARG(tokens > 0 && patch_dim > 0 && voxels > 0, "plan_create_mapped: tokens %d / patch_dim %d / voxels %ld must be positive", tokens, patch_dim, voxels);
+    V4H_CHECK_ARG(voxels < (1L << 31), "plan_create_mapped: %ld voxels per sample do not fit the int32 index map", voxels);
+  }
   V4H_CHECK_ARG(c->depth >= 1, "plan_create: depth %d", c->depth);
   V4H_CHECK_ARG(c->hidden_dim % c->num_heads == 0, "dim should be divisible by num_heads");
   V4H_CHECK_ARG(c->hidden_dim % 96 == 0 || c->hidden_dim % 32 == 0, "plan_create: hidden_dim %d must be a multiple of 32", c->hidden_dim);
@@ -92,10 +99,19 @@ extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) {
   v4h_plan* p = new v4h_plan();
   p->cfg = *c;
   p->mode = (Mode)c->mode;
-  p->pg = PatchGeom{c->shape[0], c->shape[1], c->shape[2], c->patch_shape[0], c->patch_shape[1], c->patch_shape[2],
-                    c->shape[0] / c->patch_shape[0], c->shape[1] / c->patch_shape[1], c->shape[2] / c->patch_shape[2]};
-  p->T = p->pg.l * p->pg.a * p->pg.r;
-  p->P = c->patch_shape[0] * c->patch_shape[1] * c->patch_shape[2];
+  p->mapped = mapped;
+  if (!mapped) {
+    p->pg = PatchGeom{c->shape[0], c->shape[1], c->shape[2], c->patch_shape[0], c->patch_shape[1], c->patch_shape[2],
+                      c->shape[0] / c->patch_shape[0], c->shape[1] / c->patch_shape[1], c->shape[2] / c->patch_shape[2]};
+    p->T = p->pg.l * p->pg.a * p->pg.r;
+    p->P = c->patch_shape[0] * c->patch_shape[1] * c->patch_shape[2];
+    p->V = (long)c->shape[0] * c->shape[1] * c->shape[2];
+  } else {
+    p->pg = PatchGeom{};
+    p->T = tokens;
+    p->P = patch_dim;
+    p->V = voxels;
+  }
   p->Ppad = round_up(p->P, 32);
   p->D = c->hidden_dim;
   p->H = c->num_heads;
@@ -118,6 +134,16 @@ extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) {
   }
   add(p->P, D); add(p->P, 0); add(2 * D, D); add(2 * D, 0);
   *out = p;
+  return V4H_OK;
+}
+extern "C" int32_t v4h_plan_create(const v4h_config* c, v4h_plan** out) { return plan_create_impl(c, false, 0, 0, 0, out); }
+extern "C" int32_t v4h_plan_create_mapped(const v4h_config* c, int32_t tokens, int32_t patch_dim, int64_t voxels, v4h_plan** out) {
+  return plan_create_impl(c, true, tokens, patch_dim, (long)voxels, out);
+}
+// geometry-dependent steps: regular grid (closed-form index arithmetic) or caller-provided tables
+static int check_geom(const v4h_plan* p, const int32_t* map, const float* pos, const char* who) {
+  if (p->mapped) V4H_CHECK_ARG(map != nullptr && pos != nullptr, "%s: a plan made by v4h_plan_create_mapped needs d_patch_map and d_pos", who);
+  else V4H_CHECK_ARG(map == nullptr, "%s: d_patch_map given to a regular-grid plan (use v4h_plan_create_mapped)", who);
   return V4H_OK;
 }
 extern "C" void v4h_plan_destroy(v4h_plan* p) {
@@ -323,8 +349,9 @@ static int check_common(const v4h_plan* p, int B, const void* const* params, voi
 
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* const* params, const float* x, const float* t, const float* cnd, float* out,
-                                   void* ws, size_t ws_bytes, int32_t training, void* stream) {
+                                   void* ws, size_t ws_bytes, int32_t training, void* stream, const int32_t* pmap, const float* pos) {
   RUN(check_common(p, B, params, ws, ws_bytes, training != 0, "vit_forward"));
+  RUN(check_geom(p, pmap, pos, "vit_forward"));
   V4H_CHECK_ARG(x && t && cnd && out, "vit_forward: null tensor");
   Ctx c{*p, B, params, WS(), (hipStream_t)stream};
   layout(*p, B, training != 0, (char*)ws, c.w);
@@ -348,8 +375,10 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
-  RUN(patchify(m, x, w.xp, B, p->pg, p->P, p->Ppad, c.s));
-  RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
+  if (pmap) RUN(patchify_map(m, false, x, pmap, w.xp, B, p->V, T, p->P, p->Ppad, c.s));
+  else RUN(patchify(m, x, w.xp, B, p->pg, p->P, p->Ppad, c.s));
+  if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, w.pe, T, D, c.s));
+  else RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
   {
     GemmArgs a = gargs(w.xp, p->Ppad, c.W(P_XW), p->Ppad, BT, D, p->Ppad);
     a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T;
@@ -405,7 +434,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, 2 * D, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
   {
     GemmArgs a = gargs(w.uf, D, c.W(p->fin(F_LINW)), D, BT, p->Ppad, D);
-    a.e.out = out; a.e.bias = w.linb_pad; a.e.T = T; a.e.pg = p->pg; a.e.P = p->P;
+    a.e.out = out; a.e.bias = w.linb_pad; a.e.T = T; a.e.pg = p->pg; a.e.P = p->P; a.e.map = pmap; a.e.V = p->V;
     RUN(gemm_fwd(m, EPI_UNPATCH, a, c.s));
   }
   return V4H_OK;
@@ -424,8 +453,9 @@ static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int 
 }
 
 extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
-                                    int32_t stage_first, int32_t stage_last, void* stream) {
+                                    int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos) {
   RUN(check_common(p, B, params, ws, ws_bytes, true, "vit_backward"));
+  RUN(check_geom(p, pmap, pos, "vit_backward"));
   V4H_CHECK_ARG(grads != nullptr, "vit_backward: null gradient table");
   for (int i = 0; i < p->nparams(); ++i) V4H_CHECK_ARG(grads[i] != nullptr && ((uintptr_t)grads[i] % 16) == 0, "vit_backward: gradient %d null or not 16-byte aligned", i);
   const int nst = p->depth + 2;
@@ -444,7 +474,8 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
     if (st == 0) {
       hipError_t e = hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, c.s);
       if (e != hipSuccess) { v4h_set_error("vit_backward: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
-      RUN(patchify(m, dout, w.dvp, B, p->pg, p->P, p->Ppad, c.s));
+      if (pmap) RUN(patchify_map(m, false, dout, pmap, w.dvp, B, p->V, T, p->P, p->Ppad, c.s));
+      else RUN(patchify(m, dout, w.dvp, B, p->pg, p->P, p->Ppad, c.s));
       RUN(wgrad(c, w.dvp, p->Ppad, p->Ppad, w.uf, D, D, BT, w.glin, D, w.glinb));
       GemmArgs a = gargs(w.dvp, p->Ppad, c.W(p->fin(F_LINW)), D, BT, D, p->Ppad);
       a.e.out = w.du; a.e.ldo = D;
@@ -515,7 +546,8 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       // --- embedders (nn/vit.py:76-82,193-199) ---
       RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Ppad, p->Ppad, BT, w.gxw, p->Ppad, (float*)grads[P_XB]));
       RUN(unpad_f32(w.gxw, p->Ppad, (float*)grads[P_XW], D, p->P, c.s));
-      RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
+      if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
+      else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
       // c_embedder
       RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
@@ -595,15 +627,21 @@ extern "C" int32_t v4h_op_ln_modulate_fwd(int32_t mode, const float* x, const fl
   V4H_CHECK_ARG((mode == 0 || mode == 1) && x && shift && scale && u && B > 0 && T > 0, "op_ln_modulate_fwd: bad argument");
   return ln_modulate_fwd((Mode)mode, x, shift, scale, ld_mod, u, mean, rstd, B * T, T, D, (hipStream_t)s);
 }
-extern "C" int32_t v4h_op_patchify(const v4h_plan* p, const float* vox, float* tok, int32_t B, void* s) {
+extern "C" int32_t v4h_op_patchify(const v4h_plan* p, const float* vox, float* tok, int32_t B, void* s, const int32_t* pmap) {
   V4H_CHECK_ARG(p && vox && tok && B > 0, "op_patchify: bad argument");
+  V4H_CHECK_ARG(p->mapped == (pmap != nullptr), "op_patchify: d_patch_map must be given exactly for mapped plans");
+  if (pmap) return patchify_map(MODE_F32, true, vox, pmap, tok, B, p->V, p->T, p->P, p->P, (hipStream_t)s);
   return patchify(MODE_F32, vox, tok, B, p->pg, p->P, p->P, (hipStream_t)s);
 }
-extern "C" int32_t v4h_op_unpatchify(const v4h_plan* p, const float* tok, float* vox, int32_t B, void* s) {
+extern "C" int32_t v4h_op_unpatchify(const v4h_plan* p, const float* tok, float* vox, int32_t B, void* s, const int32_t* pmap) {
   V4H_CHECK_ARG(p && vox && tok && B > 0, "op_unpatchify: bad argument");
+  V4H_CHECK_ARG(p->mapped == (pmap != nullptr), "op_unpatchify: d_patch_map must be given exactly for mapped plans");
+  if (pmap) return unpatchify_map_f32(tok, p->P, pmap, vox, B, p->V, p->T, p->P, (hipStream_t)s);
   return unpatchify_f32(tok, p->P, vox, B, p->pg, p->P, (hipStream_t)s);
 }
-extern "C" int32_t v4h_op_pos_embed(const v4h_plan* p, const float* freqs, float* pe, void* s) {
+extern "C" int32_t v4h_op_pos_embed(const v4h_plan* p, const float* freqs, float* pe, void* s, const float* pos) {
   V4H_CHECK_ARG(p && freqs && pe, "op_pos_embed: bad argument");
+  V4H_CHECK_ARG(!p->mapped || pos != nullptr, "op_pos_embed: mapped plans need d_pos");
+  if (pos) return pos_embed_fwd_pos(freqs, pos, pe, p->T, p->D, (hipStream_t)s);
   return pos_embed_fwd(freqs, pe, p->pg, p->D, (hipStream_t)s);
 }

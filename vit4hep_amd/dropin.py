@@ -4,7 +4,7 @@
     _target_: nn.vit.ViT                                                               (configs/model/cfm/cfm_ds2_electrons.yaml:14)
 
 Call ``vit4hep_amd.dropin.install()`` before ``hydra.utils.instantiate(cfg.model)`` (reference
-experiments/base_experiment.py:116), e.g. at the top of main.py.  Only the three hot-path modules are aliased; every other
+experiments/base_experiment.py:116), e.g. at the top of main.py.  Only the hot-path modules (network, CFM base, trajectories and the CFM wrappers of each dataset) are aliased; every other
 reference module (experiments.base_experiment, datasets, transforms, ...) keeps resolving to the reference's own files.
 """
 
@@ -19,6 +19,9 @@ ALIASES = {
     "models.base_model": "vit4hep_amd.models.base_model",
     "models.trajectories": "vit4hep_amd.models.trajectories",
     "experiments.calochallenge.calochallenge_cfm.model": "vit4hep_amd.experiments.calochallenge.calochallenge_cfm.model",
+    "experiments.calogan.model": "vit4hep_amd.experiments.calogan.model",
+    "experiments.calohadronic.model": "vit4hep_amd.experiments.calohadronic.model",
+    "experiments.lemurs.model": "vit4hep_amd.experiments.lemurs.model",
 }
 _installed = []
 

@@ -2,7 +2,8 @@
 
 Voxel grid <-> patch tokens around the ViT.  When ``net`` is this package's ViT the patching is fused into the
 HIP forward/backward (voxels in, voxels out); ``to_patches`` / ``from_patches`` remain available as HIP kernels.
-The irregular-layer ``CaloChallengeCFM_DS1`` variant of the reference is not on the ds2/ds3 path.
+``CaloChallengeCFM_DS1`` (irregular layers: one patch segment per calorimeter layer) runs through the same kernels with an
+index-map geometry (vit4hep_amd/patching.py).
 """
 
 from __future__ import annotations
@@ -11,11 +12,9 @@ import torch
 
 from ....autograd import _patchify, _unpatchify
 from ....models.base_model import CFM
+from ....models.segmented import SegmentedPatching
+from ....models.segmented import unwrap as _unwrap
 from ....nn.vit import ViT
-
-
-def _unwrap(net):
-    return net.module if hasattr(net, "module") and not isinstance(net, ViT) else net
 
 
 class CaloChallengeCFM(CFM):
@@ -58,3 +57,16 @@ class CaloChallengeCFM(CFM):
         """reference model.py:68-94"""
         x_T = torch.randn((batch.shape[0], self.in_channels, *self.shape), dtype=batch.dtype, device=batch.device)
         return self._sample_from(x_T, batch)
+
+
+class CaloChallengeCFM_DS1(SegmentedPatching, CaloChallengeCFM):
+    """Dataset-1 (photons / pions) shape model: per-layer segments with a shared patch shape (reference model.py:97-173)."""
+
+    def __init__(self, net, list_shape, list_edges, patch_shape, in_channels=1, time_distribution="uniform", trajectory="linear", odeint_kwargs=None,
+                 *args, **kwargs):
+        CFM.__init__(self, None, time_distribution, trajectory, odeint_kwargs, *args, **kwargs)
+        self.shape = [int(s) for s in self.shape]
+        self.patch_shape = [int(p) for p in patch_shape]
+        self.in_channels = in_channels
+        self.num_patches = [s // p for s, p in zip(self.shape, self.patch_shape)]  # what the reference's base constructor leaves behind
+        self._init_segments(net, list_shape, list_edges, [self.patch_shape] * len(list(list_shape)))

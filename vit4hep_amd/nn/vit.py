@@ -111,8 +111,8 @@ class ViT(nn.Module):
         if float(self.attn_drop) != 0.0 or float(self.proj_drop) != 0.0:
             raise NotImplementedError("vit4hep_amd: dropout > 0 is not on the shape-CFM path")
         self.num_patches = [list(int(v) for v in seg) for seg in self.num_patches]
-        if self.dim != 3 or len(self.num_patches) != 1 or len(self.num_patches[0]) != 3:
-            raise NotImplementedError("vit4hep_amd: only a single 3-D patch segment [[l, a, r]] is supported (ds2/ds3 shape models)")
+        if self.dim != 3 or len(self.num_patches) < 1 or any(len(seg) != 3 for seg in self.num_patches):
+            raise NotImplementedError("vit4hep_amd: num_patches must be a list of 3-D patch segments [[l, a, r], ...]")
 
         D = int(self.hidden_dim)
         self.x_embedder = nn.Linear(int(self.patch_dim), D)
@@ -127,23 +127,31 @@ class ViT(nn.Module):
         self.final_layer = FinalLayer(D, int(self.patch_dim), int(self.out_channels), x_out=1)
         self.initialize_weights()
 
-        self._geometry = None  # (shape, patch_shape), set by CaloChallengeCFM; a consistent default otherwise
+        # geometry: ("grid", shape, patch_shape) set by CaloChallengeCFM / LEMURSCFM, or ("map", key, voxels) set by the
+        # multi-segment wrappers; a consistent default otherwise
+        self._geometry = None
+        self._patch_map = None  # host int32 (T, P) index table of a "map" geometry
+        self._map_holes = False
         self._plan = None
         self._infer_ws = {}
+        self._dev_tables = None
 
     # ------------------------------------------------------------------ reference-visible helpers
     def create_meshgrid(self):
-        """Buffers pos_z/pos_y/pos_x on the patch grid (reference nn/vit.py:137-154), single segment."""
-        l, a, r = self.num_patches[0]
-        z, y, x = torch.meshgrid(torch.arange(l) / l, torch.arange(a) / a, torch.arange(r) / r, indexing="ij")
-        return z.flatten().clone(), y.flatten().clone(), x.flatten().clone()  # real storage (meshgrid returns expanded views)
+        """Buffers pos_z/pos_y/pos_x on the patch grid (reference nn/vit.py:137-154): z over the concatenated l-grids of all
+        segments, y / x per segment."""
+        from ..patching import multi_segment_meshgrid
+
+        z, y, x = multi_segment_meshgrid(self.num_patches)
+        return torch.from_numpy(z).clone(), torch.from_numpy(y).clone(), torch.from_numpy(x).clone()
 
     def learnable_pos_embedding(self):
         """(T, D) table from pos_embed_freqs, computed by the HIP kernel (reference nn/vit.py:156-162)."""
         plan = self._get_plan()
         freqs = _lib.require_cuda(self.pos_embed_freqs.detach(), "pos_embed_freqs")
+        _, pos = self.device_tables(freqs.device, force_pos=True)
         pe = torch.empty((self.num_tokens, int(self.hidden_dim)), dtype=torch.float32, device=freqs.device)
-        _lib.check(_lib.load().v4h_op_pos_embed(plan.handle, _lib.ptr(freqs), _lib.ptr(pe), _lib.stream_ptr(freqs.device)), "v4h_op_pos_embed")
+        _lib.check(_lib.load().v4h_op_pos_embed(plan.handle, _lib.ptr(freqs), _lib.ptr(pe), _lib.stream_ptr(freqs.device), _lib.ptr(pos)), "v4h_op_pos_embed")
         return pe
 
     def initialize_weights(self):
@@ -162,28 +170,79 @@ class ViT(nn.Module):
     # ------------------------------------------------------------------ HIP plumbing
     @property
     def num_tokens(self):
-        l, a, r = self.num_patches[0]
-        return l * a * r
+        # the position buffers made at construction define the token count, as in the reference (wrappers may overwrite
+        # self.num_patches afterwards: calochallenge_cfm/model.py:141)
+        return int(self.pos_x.numel())
+
+    def _reset_geometry(self, geom):
+        self._geometry, self._plan, self._infer_ws, self._dev_tables = geom, None, {}, None
 
     def set_geometry(self, shape, patch_shape):
+        """Regular grid: closed-form patch indexing inside the kernels."""
         shape, patch_shape = [int(s) for s in shape], [int(s) for s in patch_shape]
-        if [s // p for s, p in zip(shape, patch_shape)] != self.num_patches[0] or math.prod(patch_shape) * int(self.out_channels) != int(self.patch_dim):
-            raise ValueError(f"geometry shape={shape} patch_shape={patch_shape} does not match num_patches={self.num_patches} patch_dim={self.patch_dim}")
-        if self._geometry != (shape, patch_shape):
-            self._geometry, self._plan, self._infer_ws = (shape, patch_shape), None, {}
+        n = [s // p for s, p in zip(shape, patch_shape)]
+        if math.prod(n) != self.num_tokens or math.prod(patch_shape) * int(self.out_channels) != int(self.patch_dim):
+            raise ValueError(f"geometry shape={shape} patch_shape={patch_shape} does not match num_tokens={self.num_tokens} patch_dim={self.patch_dim}")
+        geom = ("grid", shape, patch_shape)
+        if self._geometry != geom:
+            self._patch_map, self._map_holes = None, False
+            self._reset_geometry(geom)
+
+    def set_patch_map(self, patch_map, voxels):
+        """General geometry: ``patch_map`` int32 (T, P) = voxel index (within a sample of ``voxels`` values) of every token feature,
+        -1 for none (vit4hep_amd.patching.segment_patch_map builds it for the multi-segment wrappers)."""
+        import numpy as np
+
+        pm = np.ascontiguousarray(np.asarray(patch_map, dtype=np.int32))
+        if pm.shape != (self.num_tokens, int(self.patch_dim)):
+            raise ValueError(f"patch map shape {pm.shape} does not match (num_tokens={self.num_tokens}, patch_dim={int(self.patch_dim)})")
+        if pm.size and (int(pm.max()) >= int(voxels) or int(pm.min()) < -1):
+            raise ValueError(f"patch map entries must lie in [-1, {int(voxels)})")
+        if self._geometry is not None and self._geometry[0] == "map" and self._geometry[2] == int(voxels) and np.array_equal(self._patch_map, pm):
+            return
+        self._patch_map = pm
+        self._map_holes = bool(np.unique(pm[pm >= 0]).size != int(voxels))
+        self._reset_geometry(("map", None, int(voxels)))
 
     def geometry(self):
         if self._geometry is None:  # any geometry whose patching is the identity on (T, P) token rows will do
-            l, a, r = self.num_patches[0]
             P = int(self.patch_dim)
-            self._geometry = ([l * P, a, r], [P, 1, 1])
+            if len(self.num_patches) == 1 and math.prod(self.num_patches[0]) == self.num_tokens:
+                l, a, r = self.num_patches[0]
+                self._geometry = ("grid", [l * P, a, r], [P, 1, 1])
+            else:
+                import numpy as np
+
+                self.set_patch_map(np.arange(self.num_tokens * P, dtype=np.int32).reshape(self.num_tokens, P), self.num_tokens * P)
         return self._geometry
+
+    def voxel_shape(self):
+        """Per-sample shape (without batch / channel) of the tensors the fused forward consumes and produces."""
+        g = self.geometry()
+        return tuple(g[1]) if g[0] == "grid" else (g[2],)
+
+    def map_has_holes(self):
+        self.geometry()
+        return self._map_holes
+
+    def device_tables(self, device, force_pos=False):
+        """(patch map, position table) on ``device`` for a mapped geometry, (None, None) for a regular grid."""
+        g = self.geometry()
+        if g[0] == "grid" and not force_pos:
+            return None, None
+        key = (str(device), self.pos_x.data_ptr(), self.pos_x._version, self.pos_y._version, self.pos_z._version, id(self._patch_map))
+        if self._dev_tables is None or self._dev_tables[0] != key:
+            pos = torch.cat([self.pos_x.detach().reshape(-1), self.pos_y.detach().reshape(-1), self.pos_z.detach().reshape(-1)]).to(device=device, dtype=torch.float32).contiguous()
+            pm = None if self._patch_map is None else torch.from_numpy(self._patch_map).to(device).contiguous()
+            self._dev_tables = (key, pm, pos)
+        return self._dev_tables[1], self._dev_tables[2]
 
     def _get_plan(self):
         if self._plan is None:
-            shape, patch_shape = self.geometry()
+            g = self.geometry()
+            shape, patch_shape, mapped = (g[1], g[2], None) if g[0] == "grid" else (None, None, (self.num_tokens, int(self.patch_dim), g[2]))
             self._plan = _lib.Plan(shape, patch_shape, self.condition_dim, self.hidden_dim, self.depth, self.num_heads,
-                                   int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode)
+                                   int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped)
             got = [tuple(p.shape) for p in self.parameter_list()]
             if got != self._plan.shapes:
                 raise RuntimeError(f"parameter inventory differs from the library's: {got} vs {self._plan.shapes}")
@@ -212,12 +271,12 @@ class ViT(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x, t, c):
         """x: patch tokens (B, T, P) as in the reference (nn/vit.py:185-206) -> (B, T, P);
-        or voxels (B, 1, L, A, R) -> voxels, which skips two layout passes (used by CaloChallengeCFM)."""
+        or voxels (B, 1, L, A, R) / (B, 1, n_voxels) -> voxels, which skips two layout passes (used by the CFM wrappers)."""
         from ..autograd import vit_apply
 
-        if x.dim() == 3:
-            return vit_apply(self, x, t, c, patches_io=True)
-        return vit_apply(self, x, t, c, patches_io=False)
+        # (B, T, P) tokens; anything else is voxels ((B, 1, n_voxels) of a mapped geometry is 3-D too)
+        patches_io = x.dim() == 3 and tuple(x.shape[1:]) == (self.num_tokens, int(self.patch_dim))
+        return vit_apply(self, x, t, c, patches_io=patches_io)
 
 
 def modulate(x, shift, scale):

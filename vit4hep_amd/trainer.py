@@ -32,8 +32,7 @@ class CFMTrainer:
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
 
         self.model = model
-        self.net = _unwrap(model.net)
-        self.net.set_geometry(model.shape, model.patch_shape)
+        self.net = model._core() if hasattr(model, "_core") else _unwrap(model.net)  # _core() (re)binds the wrapper's geometry to the net
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.clip = float(clip_grad_norm) if clip_grad_norm is not None else None
         self.iterations = int(iterations)
