@@ -1,7 +1,8 @@
 """bench.py - CFM train steps/s of the CaloChallenge-ds2 shape ViT (depth 6, hidden 480, 6 heads, mlp 1920; bs = 128 per GPU)
 on N MI355X, through the HIP path, plus the MFMA roofline fraction and the CPU-oracle baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode bf16|f32] [--workload ds2|ds3|ds2_d2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode bf16|f32] [--workload ds2|ds3|ds2_d2|lemurs|ds1_photons|ds1_pions|calogan|calohad]
+                    [--no-cpu-baseline] [--no-op-rates]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one BaseExperiment._step of the reference (experiments/base_experiment.py:555-602) on one synthetic batch per GPU:
@@ -18,7 +19,12 @@ import os
 import sys
 import time
 
-import torch
+# More hardware queues than HIP's default 4, before the runtime starts: the weight-gradient stream, torch's communication stream
+# and RCCL's own streams must not be multiplexed onto the compute stream's queue (the library also gives its
+# side stream its own priority class, which is what makes the overlap robust when this variable is not set).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -30,12 +36,37 @@ MEASURED_HBM_BYTES_PER_STEP = {("ds2", "bf16"): 2 * 4.879e9 + 5.130e9}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector rate
 
+def _grid(shape, patch, depth, B, desc, cond=46, kind="calochallenge"):
+    return {"kind": kind, "shape": tuple(shape), "segments": [(tuple(shape), tuple(patch))], "depth": depth, "B": B, "cond": cond, "desc": desc}
+
+
+def _segs(kind, list_shape, list_patch, cond, B, desc, depth=6):
+    return {"kind": kind, "shape": (sum(s[0] * s[1] * s[2] for s in list_shape),), "segments": [(tuple(s), tuple(p)) for s, p in zip(list_shape, list_patch)],
+            "depth": depth, "B": B, "cond": cond, "desc": desc}
+
+
 WORKLOADS = {
-    # name: (shape, patch_shape, depth, per-GPU batch, description)
-    "ds2": ((45, 16, 9), (3, 16, 1), 6, 128, "CaloChallenge-ds2 shape CFM, full ViT (depth 6), bs=128 per GPU"),
-    "ds3": ((45, 50, 18), (3, 10, 3), 6, 64, "CaloChallenge-ds3 shape CFM, full ViT (depth 6), bs=64 per GPU"),
-    "ds2_d2": ((45, 16, 9), (3, 16, 1), 2, 8, "CaloChallenge-ds2 shape CFM, ViT depth 2, bs=8 (reference CPU-runnable case)"),
+    # the headline (BASELINE.json) and its siblings: regular voxel grids
+    "ds2": _grid((45, 16, 9), (3, 16, 1), 6, 128, "CaloChallenge-ds2 shape CFM, full ViT (depth 6), bs=128 per GPU"),
+    "ds3": _grid((45, 50, 18), (3, 10, 3), 6, 64, "CaloChallenge-ds3 shape CFM, full ViT (depth 6), bs=64 per GPU"),
+    "ds2_d2": _grid((45, 16, 9), (3, 16, 1), 2, 8, "CaloChallenge-ds2 shape CFM, ViT depth 2, bs=8 (reference CPU-runnable case)"),
+    # the other ViT-CFM geometries of the reference; batch sizes of configs/training/cfm/shape*.yaml
+    "lemurs": _grid((45, 16, 9), (3, 16, 1), 6, 64, "LEMURS shape CFM (ds2 grid, 53 conditions), bs=64 per GPU", cond=53, kind="lemurs"),
+    "ds1_photons": _segs("ds1", [(1, 8, 5), (1, 16, 10), (1, 19, 10), (1, 5, 5), (1, 5, 5)], [(1, 1, 5)] * 5, 6, 64,
+                         "CaloChallenge-ds1 photons shape CFM (5 layer segments, 88 tokens), bs=64 per GPU"),
+    "ds1_pions": _segs("ds1", [(1, 8, 5), (1, 10, 10), (1, 10, 10), (1, 5, 5), (1, 15, 10), (1, 16, 10), (1, 10, 5)], [(1, 1, 5)] * 7, 8, 64,
+                       "CaloChallenge-ds1 pions shape CFM (7 layer segments, 125 tokens), bs=64 per GPU"),
+    "calogan": _segs("calogan", [(1, 96, 3), (1, 12, 12), (1, 6, 12)], [(1, 6, 1), (1, 2, 3), (1, 2, 3)], 4, 64,
+                     "CaloGAN e+ shape CFM (3 layer segments, 84 tokens), bs=64 per GPU"),
+    "calohad": _segs("calohad", [(10, 15, 15), (48, 30, 30)], [(5, 5, 3), (3, 5, 5)], 59, 32,
+                     "CaloHadronic shape CFM (ECal + HCal segments, 606 tokens of 75), bs=32 per GPU"),
 }
+
+
+def tokens_and_patch_dim(w):
+    T = sum((s[0] // p[0]) * (s[1] // p[1]) * (s[2] // p[2]) for s, p in w["segments"])
+    p = w["segments"][0][1]
+    return T, p[0] * p[1] * p[2]
 
 
 def fwd_flops_per_sample(T, P, depth, D=480, M=1920, K=46, F=256):
@@ -43,16 +74,37 @@ def fwd_flops_per_sample(T, P, depth, D=480, M=1920, K=46, F=256):
     return depth * T * (2 * D * 3 * D + 2 * D * D + 4 * D * M + 4 * T * D) + 4 * P * D * T + (depth * 12 * D * D + 4 * D * D + 2 * (K * D + D * D) + 2 * (F * D + D * D))
 
 
-def build_model(shape, patch_shape, depth, mode, device):
+def build_model(w, mode, device):
     from vit4hep_amd import CaloChallengeCFM, ViT
 
-    l, a, r = (s // p for s, p in zip(shape, patch_shape))
-    P = patch_shape[0] * patch_shape[1] * patch_shape[2]
-    net = ViT({"dim": 3, "condition_dim": 46, "hidden_dim": 480, "out_channels": 1, "depth": depth, "num_heads": 6, "mlp_ratio": 4, "attn_drop": 0.0,
+    T, P = tokens_and_patch_dim(w)
+    num_patches = [[s[0] // p[0], s[1] // p[1], s[2] // p[2]] for s, p in w["segments"]]
+    net = ViT({"dim": 3, "condition_dim": w["cond"], "hidden_dim": 480, "out_channels": 1, "depth": w["depth"], "num_heads": 6, "mlp_ratio": 4, "attn_drop": 0.0,
                "proj_drop": 0.0, "pos_embedding_coords": "cylindrical", "temperature": 10000, "learn_pos_embed": True, "causal_attn": False,
-               "checkpoint_grads": False, "num_patches": [[l, a, r]], "patch_dim": P, "use_torch_sdpa": False, "amd_mode": mode})
-    model = CaloChallengeCFM(net, list(patch_shape), in_channels=1, time_distribution="uniform", trajectory="linear",
-                             odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}}, shape=list(shape))
+               "checkpoint_grads": False, "num_patches": num_patches, "patch_dim": P, "use_torch_sdpa": False, "amd_mode": mode})
+    common = dict(in_channels=1, time_distribution="uniform", trajectory="linear", odeint_kwargs={"method": "rk4", "options": {"step_size": 0.05}},
+                  shape=list(w["shape"]))
+    list_shape = [list(s) for s, _ in w["segments"]]
+    list_edges = [s[0] * s[1] * s[2] for s in list_shape]
+    list_patch = [list(p) for _, p in w["segments"]]
+    if w["kind"] == "calochallenge":
+        model = CaloChallengeCFM(net, list_patch[0], **common)
+    elif w["kind"] == "lemurs":
+        from vit4hep_amd.experiments.lemurs.model import LEMURSCFM
+
+        model = LEMURSCFM(net, list_patch[0], **common)
+    elif w["kind"] == "ds1":
+        from vit4hep_amd.experiments.calochallenge.calochallenge_cfm.model import CaloChallengeCFM_DS1
+
+        model = CaloChallengeCFM_DS1(net, list_shape, list_edges, list_patch[0], **common)
+    elif w["kind"] == "calogan":
+        from vit4hep_amd.experiments.calogan.model import CaloGANCFM
+
+        model = CaloGANCFM(net, list_shape, list_edges, list_patch, **common)
+    else:
+        from vit4hep_amd.experiments.calohadronic.model import CaloHadCFM
+
+        model = CaloHadCFM(net, list_shape, list_edges, list_patch, **common)
     # random-init weights of that architecture; the zero-initialised adaLN / output tensors (nn/vit.py:174-183) are given small
     # random values so the step does the same arithmetic as a model a few hundred iterations into training (no zero operands).
     g = torch.Generator().manual_seed(1234)
@@ -65,10 +117,10 @@ def build_model(shape, patch_shape, depth, mode, device):
     return model
 
 
-def synthetic(shape, B, seed, device):
+def synthetic(shape, B, seed, device, cond=46):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((B, 1, *shape), generator=g)
-    c = torch.cat([torch.randn((B, 45), generator=g), torch.rand((B, 1), generator=g)], dim=1)
+    c = torch.cat([torch.randn((B, cond - 1), generator=g), torch.rand((B, 1), generator=g)], dim=1)
     return x.to(device), c.to(device)
 
 
@@ -98,11 +150,15 @@ def op_rates(mode, BT, device, reps=20):
     return out
 
 
-def cpu_baseline(shape, patch_shape, depth, B, budget_s=20.0):
+def cpu_baseline(w, budget_s=20.0):
     """The CPU oracle (kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import vit_cfm_oracle as O
 
-    cfg = O.ViTConfig(shape=tuple(shape), patch_shape=tuple(patch_shape), depth=depth)
+    depth, B = w["depth"], w["B"]
+    if len(w["shape"]) == 3:
+        cfg = O.ViTConfig(shape=w["shape"], patch_shape=w["segments"][0][1], depth=depth, condition_dim=w["cond"])
+    else:
+        cfg = O.ViTConfig(shape=w["shape"], patch_shape=(), depth=depth, condition_dim=w["cond"], segments=tuple(w["segments"]))
     # the GPU box gives one GPU's share of the host: 16 cores (its os.cpu_count() reports the whole machine)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = int(os.environ.get("V4H_CPU_THREADS", min(avail, 16)))
@@ -155,13 +211,14 @@ def main():
 
     from vit4hep_amd.trainer import CFMTrainer
 
-    shape, patch_shape, depth, B, desc = WORKLOADS[args.workload]
-    model = build_model(shape, patch_shape, depth, args.mode, device)
+    w = WORKLOADS[args.workload]
+    shape, depth, B, desc = w["shape"], w["depth"], w["B"], w["desc"]
+    model = build_model(w, args.mode, device)
     if dist.is_initialized():  # same initial weights everywhere, like DDP's constructor broadcast (base_experiment.py:163)
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
-    x, c = synthetic(shape, B, seed=rank, device=device)
+    x, c = synthetic(shape, B, seed=rank, device=device, cond=w["cond"])
     torch.manual_seed(1000 + rank)
 
     def sync():
@@ -189,9 +246,8 @@ def main():
     wall = float(tmax.item())
 
     if rank == 0:
-        T = (shape[0] // patch_shape[0]) * (shape[1] // patch_shape[1]) * (shape[2] // patch_shape[2])
-        P = patch_shape[0] * patch_shape[1] * patch_shape[2]
-        flop_step = 3.0 * B * fwd_flops_per_sample(T, P, depth)  # per GPU
+        T, P = tokens_and_patch_dim(w)
+        flop_step = 3.0 * B * fwd_flops_per_sample(T, P, depth, K=w["cond"])  # per GPU
         ms_step = wall * 1e3 / args.steps
         dev_ms_step = dev_ms / args.steps
         achieved = flop_step / (dev_ms_step * 1e-3) / 1e12
@@ -220,7 +276,7 @@ def main():
         if world == 1 and not args.no_op_rates:
             rec["gemm_ops"] = op_rates(args.mode, B * T, device)
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(shape, patch_shape, depth, B)
+            rec["cpu_baseline"] = cpu_baseline(w)
             rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)
         print(json.dumps(rec), flush=True)
     if dist.is_initialized():

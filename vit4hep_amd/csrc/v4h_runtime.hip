@@ -45,6 +45,7 @@ struct v4h_plan {
   // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev[8] = {};
+  mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block)
   mutable int evi = 0;
   mutable bool side_ok = false;
 };
@@ -54,9 +55,21 @@ static int side_init(const v4h_plan& p) {
   if (p.side_ok) return V4H_OK;
   const char* e = getenv("V4H_WGRAD_OVERLAP");
   if (e && e[0] == '0') g_overlap_wgrad = false;
-  if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
+  // HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); two streams that land on the same queue run
+  // their kernels back to back.  Measured: after torch.distributed + a communication stream exist, a plain side stream shares the
+  // main stream's queue and ALL overlap is lost (144.8 vs 166.9 steps/s).  Streams of another priority class get their own queue.
+  const char* pe = getenv("V4H_SIDE_PRIORITY");
+  int least = 0, greatest = 0;
+  hipError_t se;
+  if ((!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+    se = hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, greatest);
+  else
+    se = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
+  if (se != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreateWithFlags(&p.evS[i], hipEventDisableTiming) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   p.side_ok = true;
   return V4H_OK;
 }
@@ -70,6 +83,21 @@ static int side_wait_main(const v4h_plan& p, hipStream_t main) {
 static int main_wait_side(const v4h_plan& p, hipStream_t main) {
   hipEvent_t e = p.ev[p.evi++ & 7];
   if (hipEventRecord(e, p.side) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) { v4h_set_error("join failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
+
+// Lagged joins.  The weight-gradient stream only READS the backward temporaries (dy, dhpre, dqkv); the main stream must not
+// overwrite one before its reader has finished.  Instead of joining the streams at every such point (main stalls for the side
+// stream's tail + the cross-stream signal latency, measured 7-13 us each, 12 per step), the side stream drops a mark after each
+// weight gradient and the main stream waits for the mark just before the NEXT write of that buffer - half a block to a full
+// block later, when the mark has normally long been reached.
+enum { S_FC2 = 0, S_FC1, S_PROJ, S_QKV };
+static int side_mark(const v4h_plan& p, int which) {
+  if (hipEventRecord(p.evS[which], p.side) != hipSuccess) { v4h_set_error("mark failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
+static int main_wait_mark(const v4h_plan& p, int which, hipStream_t main) {
+  if (hipStreamWaitEvent(main, p.evS[which], 0) != hipSuccess) { v4h_set_error("wait for mark failed"); return V4H_ERR_HIP; }
   return V4H_OK;
 }
 
@@ -149,6 +177,7 @@ static int check_geom(const v4h_plan* p, const int32_t* map, const float* pos, c
 extern "C" void v4h_plan_destroy(v4h_plan* p) {
   if (p && p->side_ok) {
     for (int i = 0; i < 8; ++i) hipEventDestroy(p->ev[i]);
+    for (int i = 0; i < 4; ++i) hipEventDestroy(p->evS[i]);
     hipStreamDestroy(p->side);
   }
   delete p;
@@ -179,7 +208,7 @@ struct WS {
   std::vector<float*> dmod;
   float *dmodf, *dsilu, *gxw, *gc0w, *glin, *glinb;
   float *dxA, *dxB, *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
-  char *dvp, *dy, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dx0_t;
+  char *dvp, *dy, *dy2, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
   size_t total;
 };
 
@@ -265,6 +294,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
     w.dy = take(BT * D * es);
+    w.dy2 = take(BT * D * es);
     w.dhpre = take(BT * M * es);
     w.du = take(BT * D * es);
     w.dof = take(BT * D * es);
@@ -498,38 +528,46 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       float* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
       const bool ov = g_overlap_wgrad;
       hipStream_t ws_ = ov ? p->side : c.s;  // stream of the weight-gradient contractions
+      // marks of the previous block exist only if that block ran in THIS call (every call ends with a full join)
+      const bool prev = ov && st > stage_first && st - 1 >= 1;
       // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
       if (ov) RUN(side_wait_main(*p, c.s));  // dy (and h) ready
       RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_));
+      if (ov) RUN(side_mark(*p, S_FC2));
+      if (prev) RUN(main_wait_mark(*p, S_FC1, c.s));  // dhpre is about to be overwritten: its reader of the previous block must be done
       GemmArgs a = gargs(w.dy, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
       a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
       RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
       if (ov) RUN(side_wait_main(*p, c.s));  // dhpre ready
       RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_));
+      if (ov) RUN(side_mark(*p, S_FC1));
       a = gargs(w.dhpre, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      if (ov) RUN(main_wait_side(*p, c.s));  // the next kernel overwrites dy
+      if (prev) RUN(main_wait_mark(*p, S_PROJ, c.s));  // dy2 is about to be overwritten
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = 6 * D;
       l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = w.dmod[i] + 3 * D; l.dscale = w.dmod[i] + 4 * D; l.ld_dmod = 6 * D;
-      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
+      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy2; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
-      if (ov) RUN(side_wait_main(*p, c.s));  // dy ready
-      RUN(wgrad(c, w.dy, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_));
-      a = gargs(w.dy, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
+      if (ov) RUN(side_wait_main(*p, c.s));  // dy2 ready
+      RUN(wgrad(c, w.dy2, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_));
+      if (ov) RUN(side_mark(*p, S_PROJ));
+      a = gargs(w.dy2, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
       a.e.out = w.dof; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
+      if (prev) RUN(main_wait_mark(*p, S_QKV, c.s));  // dqkv is about to be overwritten
       RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, w.dqkv, B, T, p->H, p->DH, c.s));
       if (ov) RUN(side_wait_main(*p, c.s));  // dqkv ready
       RUN(wgrad(c, w.dqkv, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_));
+      if (ov) RUN(side_mark(*p, S_QKV));
       a = gargs(w.dqkv, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      if (ov) RUN(main_wait_side(*p, c.s));  // the next kernel overwrites dy; the stage's gradients are complete after it
+      if (ov) RUN(main_wait_mark(*p, S_FC2, c.s));  // dy (read by this block's fc2 weight gradient, first in the side queue) is about to be overwritten
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = 6 * D;
       l.dx_in = dx_mid; l.dshift = w.dmod[i]; l.dscale = w.dmod[i] + D; l.ld_dmod = 6 * D;
@@ -564,6 +602,9 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       RUN(wgrad(c, w.dh_small, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B]));
     }
   }
+  // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
+  // kernel is left reading a temporary the next call may overwrite.
+  if (g_overlap_wgrad && stage_last >= 1 && stage_first <= depth) RUN(main_wait_side(*p, c.s));
   return V4H_OK;
 }
 

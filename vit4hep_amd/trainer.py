@@ -113,10 +113,13 @@ class CFMTrainer:
         if W > 1:  # DDP averages gradients: fold 1/world into the seed, then SUM
             _lib.check(lib.v4h_axpby(_lib.ptr(dv), _lib.ptr(dv), _lib.ptr(dv), 1.0 / W, 0.0, dv.numel(), s), "v4h_axpby")
         self.flat_g.zero_()
-        for st, (lo, hi) in enumerate(self.stage_slices):
-            run_backward(self.net, self.p_views, self.g_views, dv, ws, st, st)
-            self.reducer.reduce_slice(lo, hi)
-        self.reducer.finish()
+        if collectives_enabled():
+            for st, (lo, hi) in enumerate(self.stage_slices):  # each call ends with a stream join: the stage's gradients are final
+                run_backward(self.net, self.p_views, self.g_views, dv, ws, st, st)
+                self.reducer.reduce_slice(lo, hi)
+            self.reducer.finish()
+        else:  # single rank: one call, so the weight-gradient stream is joined only once at the end
+            run_backward(self.net, self.p_views, self.g_views, dv, ws, 0, len(self.stage_slices) - 1)
         return self.loss
 
     def step(self, x, c, t=None, x0=None):
