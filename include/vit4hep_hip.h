@@ -67,7 +67,13 @@ size_t v4h_plan_workspace_bytes(const v4h_plan* plan, int32_t B, int32_t trainin
 /* ---- network: CaloChallengeCFM.forward = to_patches -> ViT.forward -> from_patches
  *      (calochallenge_cfm/model.py:62-66, nn/vit.py:185-206) and its backward (autograd of the same) -------- */
 /* d_params: host array of v4h_plan_num_params() device pointers to f32 tensors in the order above.
- * d_x (B,1,L,A,R) f32, d_t (B) f32, d_c (B,condition_dim) f32 -> d_out (B,1,L,A,R) f32. */
+ * d_x (B,1,L,A,R) f32, d_t (B) f32, d_c (B,condition_dim) f32 -> d_out (B,1,L,A,R) f32.
+ * `training`: bit 0 = keep every activation the backward needs (workspace sized with training = 1);
+ *             bit 1 = V4H_FWD_REUSE_OPERANDS: the previous forward on this very workspace (same plan, B, bit 0) used the same,
+ *             unchanged parameters - skip re-making their operand copies (bf16 casts, padded extents, positional table).
+ *             The ODE sampler calls the network 80 times per batch with frozen weights (calochallenge_cfm/model.py:81-92). */
+#define V4H_FWD_TRAINING 1
+#define V4H_FWD_REUSE_OPERANDS 2
 int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
                         float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream, const int32_t* d_patch_map,
                         const float* d_pos);

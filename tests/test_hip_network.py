@@ -129,6 +129,45 @@ def test_sample_batch_shape_and_determinism():
     assert a.shape == (4, 1, 45, 16, 9) and torch.equal(a, b) and torch.isfinite(a).all()
 
 
+def test_frozen_weight_operand_copies_are_reused_and_invalidated():
+    """Inference forwards keep the bf16 / padded operand copies of unchanged weights in the persistent workspace
+    (V4H_FWD_REUSE_OPERANDS); any in-place update of a parameter, by torch or by the fused trainer, refreshes them."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    fill = O.golden_fill(cfg)
+    model = U.build_models(cfg, "bf16", fill).eval()
+    net = model.net
+    x, c, _ = O.synthetic_batch(cfg, 4, 3)
+    x, c = x.to(U.DEV), c.to(U.DEV)
+    t = torch.full((4, 1), 0.3, device=U.DEV)
+    with torch.no_grad():
+        a = model.forward(x, t, c)
+        params = [p.detach() for p in net.parameter_list()]
+        assert net.operands_current(params, net.inference_workspace(4, U.DEV), mark=False)  # second call will skip the casts
+        b = model.forward(x, t, c)
+        assert torch.equal(a, b)
+        net.blocks[0].mlp.fc1.weight.mul_(1.5)  # torch in-place update bumps the version counter
+        assert not net.operands_current(params, net.inference_workspace(4, U.DEV), mark=False)
+        d = model.forward(x, t, c)
+        assert not torch.equal(a, d)
+        fresh_fill = {k: v.clone() for k, v in fill.items()}
+        fresh_fill["blocks.0.mlp.fc1.weight"] *= 1.5
+        fresh = U.build_models(cfg, "bf16", fresh_fill).eval()
+        assert torch.equal(d, fresh.forward(x, t, c))
+        # other batch size -> other workspace -> full refresh, still right
+        assert torch.equal(model.forward(x[:2], t[:2], c[:2]), fresh.forward(x[:2], t[:2], c[:2]))
+    # the fused trainer rewrites parameters through raw pointers and bumps weights_epoch
+    model.train()
+    tr = CFMTrainer(model, iterations=10)
+    with torch.no_grad():
+        before = model.forward(x, t, c).clone()
+    tr.step(x, c)
+    with torch.no_grad():
+        after = model.forward(x, t, c)
+    assert not torch.equal(before, after)
+
+
 @pytest.mark.parametrize("name", ["ds2_d2_b2", "ds2_d6_b2"])
 def test_update_step_trajectory_vs_golden(name, golden):
     """_step semantics (base_experiment.py:555-597) with the fused clip + AdamW kernels: loss trajectory and final weights."""

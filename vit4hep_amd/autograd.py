@@ -43,14 +43,20 @@ def run_forward(net, params, x_vox, t, c, training, ws=None):
     dev = x_vox.device
     if tuple(x_vox.shape) != _vox_shape(net, B):  # the kernels index by the plan's geometry: never launch on a mismatching buffer
         raise RuntimeError(f"input shape {tuple(x_vox.shape)} does not match the network geometry {_vox_shape(net, B)}")
+    flags = 1 if training else 0
     if ws is None:
-        ws = torch.empty(plan.workspace_bytes(B, training), dtype=torch.uint8, device=dev) if training else net.inference_workspace(B, dev)
+        if training:
+            ws = torch.empty(plan.workspace_bytes(B, True), dtype=torch.uint8, device=dev)
+        else:  # persistent workspace: frozen weights keep their operand copies between calls (the sampler's 80 evaluations per batch)
+            ws = net.inference_workspace(B, dev)
+            if net.operands_current(params, ws):
+                flags |= 2  # V4H_FWD_REUSE_OPERANDS
     out = torch.zeros_like(x_vox) if net.map_has_holes() else torch.empty_like(x_vox)
     tab = _lib.pointer_table(params)
     pmap, pos = net.device_tables(dev)
     _lib.check(
         _lib.load().v4h_vit_forward(plan.handle, B, tab, _lib.ptr(x_vox), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
-                                    1 if training else 0, _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos)),
+                                    flags, _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos)),
         "v4h_vit_forward",
     )
     return out, ws

@@ -380,6 +380,10 @@ static int check_common(const v4h_plan* p, int B, const void* const* params, voi
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* const* params, const float* x, const float* t, const float* cnd, float* out,
                                    void* ws, size_t ws_bytes, int32_t training, void* stream, const int32_t* pmap, const float* pos) {
+  const int32_t flags = training;
+  training = flags & 1;
+  const bool reuse = (flags & V4H_FWD_REUSE_OPERANDS) != 0;  // operand copies + positional table of these parameters are already in this workspace
+  V4H_CHECK_ARG((flags & ~3) == 0, "vit_forward: unknown flag bits 0x%x", flags);
   RUN(check_common(p, B, params, ws, ws_bytes, training != 0, "vit_forward"));
   RUN(check_geom(p, pmap, pos, "vit_forward"));
   V4H_CHECK_ARG(x && t && cnd && out, "vit_forward: null tensor");
@@ -392,7 +396,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // 0. operand copies of the weights (cast to bf16 / zero-pad awkward extents), padded condition vector
   {
     std::vector<CastPadItem> items;
-    for (int i = 0; i < p->nparams(); ++i) {
+    for (int i = 0; i < p->nparams() && !reuse; ++i) {
       if (!w.wop[i]) continue;
       int rp = p->rows[i], cp = p->cols[i];
       if (i == P_XW) cp = p->Ppad;
@@ -400,14 +404,15 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       if (i == p->fin(F_LINW)) rp = p->Ppad;
       items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
     }
-    items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
+    if (!reuse) items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
     items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
   if (pmap) RUN(patchify_map(m, false, x, pmap, w.xp, B, p->V, T, p->P, p->Ppad, c.s));
   else RUN(patchify(m, x, w.xp, B, p->pg, p->P, p->Ppad, c.s));
-  if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, w.pe, T, D, c.s));
+  if (reuse) {}
+  else if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, w.pe, T, D, c.s));
   else RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
   {
     GemmArgs a = gargs(w.xp, p->Ppad, c.W(P_XW), p->Ppad, BT, D, p->Ppad);

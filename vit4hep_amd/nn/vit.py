@@ -134,6 +134,8 @@ class ViT(nn.Module):
         self._map_holes = False
         self._plan = None
         self._infer_ws = {}
+        self._infer_sig = None
+        self.weights_epoch = 0  # bumped by code that rewrites parameters behind torch's back (the fused AdamW kernel)
         self._dev_tables = None
 
     # ------------------------------------------------------------------ reference-visible helpers
@@ -175,7 +177,7 @@ class ViT(nn.Module):
         return int(self.pos_x.numel())
 
     def _reset_geometry(self, geom):
-        self._geometry, self._plan, self._infer_ws, self._dev_tables = geom, None, {}, None
+        self._geometry, self._plan, self._infer_ws, self._dev_tables, self._infer_sig = geom, None, {}, None, None
 
     def set_geometry(self, shape, patch_shape):
         """Regular grid: closed-form patch indexing inside the kernels."""
@@ -265,8 +267,19 @@ class ViT(nn.Module):
         ws = self._infer_ws.get(key)
         if ws is None:
             self._infer_ws = {key: torch.empty(self._get_plan().workspace_bytes(B, False), dtype=torch.uint8, device=device)}
+            self._infer_sig = None
             ws = self._infer_ws[key]
         return ws
+
+    def operands_current(self, params, ws, mark=True):
+        """True when `ws` already holds the operand copies of exactly these parameter values (same storage, no in-place update
+        since: torch bumps ``_version`` on every in-place write, the fused trainer bumps ``weights_epoch``)."""
+        sig = (ws.data_ptr(), self.weights_epoch, self.pos_x.data_ptr(), self.pos_x._version, id(self._plan),
+               tuple((p.data_ptr(), p._version) for p in params))
+        same = getattr(self, "_infer_sig", None) == sig
+        if mark:
+            self._infer_sig = sig
+        return same
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, t, c):

@@ -137,6 +137,7 @@ class CFMTrainer:
                                self.step_count, s),
             "v4h_adamw_step",
         )
+        self.net.weights_epoch += 1  # parameters rewritten through raw pointers: invalidate cached operand copies (ViT.operands_current)
         out_loss = loss.clone()
         if collectives_enabled():
             dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
