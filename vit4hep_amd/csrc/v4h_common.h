@@ -143,9 +143,9 @@ V4H_DEV float dsilu_f(float x) {
 // tanh: accurate libm form in f32 (parity) mode, exp-based form in bf16 mode
 template <typename T> V4H_DEV float tanh_m(float u);
 template <> V4H_DEV float tanh_m<float>(float u) { return tanhf(u); }
-template <> V4H_DEV float tanh_m<bf16>(float u) {
-  const float e = __expf(2.0f * u);
-  return 1.0f - 2.0f / (e + 1.0f);
+template <> V4H_DEV float tanh_m<bf16>(float u) {  // v_exp_f32 + v_rcp_f32 (an IEEE division is a ~10-instruction sequence)
+  const float e = __builtin_amdgcn_exp2f(2.8853900818f * u);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 // nn.GELU(approximate="tanh")  (reference nn/vit.py:314-315)
 template <typename T> V4H_DEV float gelu_tanh_f(float x) {
@@ -165,6 +165,19 @@ template <typename T> V4H_DEV void gelu_and_grad(float x, float& y, float& dy) {
   const float t = tanh_m<T>(0.7978845608028654f * (x + 0.044715f * x * x2));
   y = 0.5f * x * (1.0f + t);
   dy = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x2);
+}
+// throughput mode: 0.5 x (1 + tanh u) = x * sigmoid(2u); one v_exp_f32, one v_rcp_f32 and a handful of FMAs per element
+//   2u = x (a + b x^2), a = 2*sqrt(2/pi), b = a * 0.044715 ;  d/dx [x s] = s + x s (1 - s) (a + 3 b x^2)
+V4H_DEV float gelu_sigmoid_arg(float x, float x2) { return x * (1.5957691216f + 0.0713548163f * x2); }
+template <> V4H_DEV void gelu_and_grad<bf16>(float x, float& y, float& dy) {
+  const float x2 = x * x;
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950409f * gelu_sigmoid_arg(x, x2)));
+  y = x * s;
+  dy = s + y * (1.0f - s) * (1.5957691216f + 0.2140644489f * x2);
+}
+template <typename T> V4H_DEV float gelu_only(float x) { return gelu_tanh_f<T>(x); }
+template <> V4H_DEV float gelu_only<bf16>(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950409f * gelu_sigmoid_arg(x, x * x)));
 }
 
 V4H_DEV float wave_sum(float v) {

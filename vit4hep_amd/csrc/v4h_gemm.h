@@ -156,10 +156,15 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       for (int r = 0; r < 8; ++r) x.v[r] += o.a.v[r] * v.v[r];
       store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, x);
     } else if constexpr (EPI == EPI_GELU) {
-      f32x8 d;
+      if (e.out) {  // training: the derivative is kept for the backward
+        f32x8 d;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
-      if (e.out) store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);  // derivative only kept for the backward
+        for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+        store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v.v[r] = gelu_only<T>(v.v[r]);
+      }
       store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
     } else if constexpr (EPI == EPI_DGELU) {
 #pragma unroll
