@@ -12,7 +12,8 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvit4hep_hip.so")
+# VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
+LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
 ABI_VERSION = 2
 MODE_F32 = 0

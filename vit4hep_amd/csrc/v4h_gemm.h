@@ -475,11 +475,17 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
   for (int x = 0; x < C::TI; ++x)
 #pragma unroll
     for (int y = 0; y < C::TJ; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Column sums of P (bias gradients of a wgrad).  Summing the P fragments costs 132 VALU instructions per K-step (bf16 unpack +
+  // adds, 4 cycles each) next to 30 MFMAs (16 cycles each): done by every wave in every K-step it made the whole wgrad
+  // VALU-bound.  Each (row tile, K-step) needs it exactly once, so the duty rotates over the ntj * WJ waves that hold the same
+  // P fragments: wave (tj, wj) sums in the K-steps with  step % (ntj * WJ) == tj * WJ + wj  (one scalar branch per K-step),
+  // in a sweep of its own so that the MFMA loop exists in one variant only (two variants of it spilled registers).
   float cs[C::TI];
 #pragma unroll
   for (int x = 0; x < C::TI; ++x) cs[x] = 0.f;
-
-  auto compute = [&](int buf) {
+  const int cs_period = a.ntj * C::WJ, cs_duty = tj * C::WJ + wj;
+  int cs_phase = 0;  // K-step index modulo cs_period (every tile of a row panel walks the same K-steps)
+  auto compute_impl = [&](int buf) {
     const char* tp = smem + buf * BUF_BYTES;
     const char* tq = tp + C::P_BYTES;
 #pragma unroll
@@ -489,17 +495,29 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
       for (int x = 0; x < C::TI; ++x) pf[x] = C::ImgP::frag(tp, wi * C::WTI + x * 16, kk, lane);
 #pragma unroll
       for (int y = 0; y < C::TJ; ++y) qf[y] = C::ImgQ::frag(tq, wj * C::WTJ + y * 16, kk, lane);
-      if constexpr (C::COLSUM) {
-#pragma unroll
-        for (int x = 0; x < C::TI; ++x)
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) cs[x] += to_f32(pf[x].v[jj]);
-      }
 #pragma unroll
       for (int x = 0; x < C::TI; ++x)
 #pragma unroll
         for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);  // (s_setprio around the cluster measured 40 % slower here)
     }
+  };
+  auto compute = [&](int buf) {  // one scalar branch per K-step, outside the MFMA cluster
+    if constexpr (C::COLSUM) {
+      const bool mine = a.colsum != nullptr && cs_phase == cs_duty;
+      if (++cs_phase == cs_period) cs_phase = 0;
+      if (mine) {  // a separate sweep over the P image (its fragments are re-read): the MFMA loop below stays one lean variant
+        const char* tp = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < C::BK; kk += 32)
+#pragma unroll
+          for (int x = 0; x < C::TI; ++x) {
+            const Frag<T> pf = C::ImgP::frag(tp, wi * C::WTI + x * 16, kk, lane);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) cs[x] += to_f32(pf.v[jj]);
+          }
+      }
+    }
+    compute_impl(buf);
   };
 
   if constexpr (C::NSTAGE == 2) {
@@ -652,7 +670,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     }
   }
   if constexpr (C::COLSUM) {
-    if (a.colsum != nullptr && tj == 0 && wj == 0) {
+    if (a.colsum != nullptr) {
 #pragma unroll
       for (int x = 0; x < C::TI; ++x) {
         float s = cs[x];
