@@ -32,8 +32,8 @@ def run(name, I, J, K, pks, qks, splitk=1):
     us = timeit(fn)
     print(f"{name:34s} I={I:6d} J={J:5d} K={K:6d} split={splitk:2d}  {us:8.1f} us  {2.0*I*J*K/us/1e6:7.1f} TFLOP/s", flush=True)
 
-cfgs = [int(c) for c in os.environ.get("CFGS", "0,20,21").split(",")]
-wcfgs = [int(c) for c in os.environ.get("WCFGS", "0,8,7").split(",")]
+cfgs = [int(c) for c in os.environ.get("CFGS", "0,20,21").split(",") if c]
+wcfgs = [int(c) for c in os.environ.get("WCFGS", "0,8,7").split(",") if c]
 for cfg in cfgs:
     lib.v4h_debug_set_gemm_cfg(cfg, 0)
     print(f"--- fwd/dgrad cfg {cfg}")
