@@ -258,8 +258,7 @@ template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_mod
 // Backward of LN+modulate fused with the gate backward of the branch below.  Grid (chunks, B): a workgroup owns
 // ROWS_PER_WG consecutive tokens of ONE sample, so the per-sample sums (dshift, dscale, dgate) are reduced in
 // registers -> LDS -> one f32 atomic per feature per workgroup.
-constexpr int LNB_ROWS = 16;
-template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
+template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const LnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int t0 = blockIdx.x * LNB_ROWS;
@@ -277,8 +276,7 @@ template <typename T, int LN_MAXV> __global__ __launch_bounds__(256) void ln_mod
       if (y) gt[n] = load4(a.gate + (long)b * a.ld_mod_gate + c);
     }
   }
-  // two token rows per iteration: all loads of both rows are issued before the first reduction (memory-level parallelism)
-  constexpr int R = 2;
+  // R token rows per iteration: all loads of these rows are issued before the first reduction (memory-level parallelism)
   for (int tb = t0 + wave * R; tb < t1; tb += 4 * R) {
     long row[R];
     bool ok[R];
@@ -584,14 +582,16 @@ int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* sca
 }
 int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 1024, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
-  const dim3 grid((a.T + LNB_ROWS - 1) / LNB_ROWS, a.B);
+  // 16 rows per workgroup, 2 rows in flight per wave: measured best (4 rows in flight or 32-48 rows per workgroup: -1...-6 % end to end)
+#define V4H_LNB_LAUNCH(TT, MAXV) hipLaunchKernelGGL((ln_modulate_bwd_kernel<TT, MAXV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
   if (a.D <= 512) {
-    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_bwd_kernel<bf16, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_modulate_bwd_kernel<float, 2>), grid, dim3(256), 0, s, a);
+    if (m == MODE_BF16) V4H_LNB_LAUNCH(bf16, 2);
+    else V4H_LNB_LAUNCH(float, 2);
   } else {
-    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_bwd_kernel<bf16, 4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((ln_modulate_bwd_kernel<float, 4>), grid, dim3(256), 0, s, a);
+    if (m == MODE_BF16) V4H_LNB_LAUNCH(bf16, 4);
+    else V4H_LNB_LAUNCH(float, 4);
   }
+#undef V4H_LNB_LAUNCH
   V4H_CHECK_LAUNCH("ln_modulate_bwd");
   return V4H_OK;
 }
