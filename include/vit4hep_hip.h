@@ -86,6 +86,41 @@ int32_t v4h_vit_backward(const v4h_plan* plan, int32_t B, const void* const* d_p
                          size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream, const int32_t* d_patch_map, const float* d_pos);
 int32_t v4h_vit_num_backward_stages(const v4h_plan* plan);
 
+/* ---- energy-model velocity field: ParallelTransformer.forward (nn/cfm/transformer_cfm.py:12-119), forward only --------------
+ * The network the reference samples the layer-energy ratios from before the shape model runs
+ * (experiments/calochallenge/experiment.py:225-247; configs/model/cfm/cfm_ds{1,2,3}*_energy.yaml: `embeds: true`, one condition
+ * token, d_model = 2 * dim_embedding = 128, 4 heads, 4 + 4 post-norm nn.Transformer layers, relu feed-forward 512).
+ * Mirrors the `param` mapping of transformer_cfm.py:21-37. */
+typedef struct v4h_energy_config {
+  int32_t dims_in;            /* 45 (ds2/ds3), 5 / 7 (ds1)                 cfm_ds2_energy.yaml:15 */
+  int32_t dims_c;             /* must be 1                                   cfm_ds2_energy.yaml:16 */
+  int32_t dim_embedding;      /* 64 -> d_model 128                           transformer_cfm.py:45   */
+  int32_t nhead;              /* 4  (head_dim 32)                                                    */
+  int32_t num_encoder_layers; /* 4                                                                   */
+  int32_t num_decoder_layers; /* 4                                                                   */
+  int32_t dim_feedforward;    /* 512                                                                 */
+  int32_t encode_t_dim;       /* 64, must equal dim_embedding                transformer_cfm.py:87-89 */
+  int32_t mode;               /* V4H_MODE_*                                                          */
+} v4h_energy_config;
+typedef struct v4h_energy_plan v4h_energy_plan;
+int32_t v4h_energy_plan_create(const v4h_energy_config* cfg, v4h_energy_plan** out);
+void v4h_energy_plan_destroy(v4h_energy_plan* plan);
+/* tensors in the module's named_parameters() order: time_embed.0.W, time_embed.1.{weight,bias}, x_embed.{weight,bias},
+ * c_embed.{weight,bias}, pos_embed_x.weight, pos_embed_c.weight, layer.{weight,bias} (= layers.0), transformer.encoder.layers.i.
+ * {self_attn.in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.*, linear2.*, norm1.*, norm2.*},
+ * transformer.encoder.norm.*, transformer.decoder.layers.i.{self_attn.*, multihead_attn.*, linear1.*, linear2.*, norm1-3.*},
+ * transformer.decoder.norm.*, layers.2.{weight,bias} */
+int32_t v4h_energy_plan_num_params(const v4h_energy_plan* plan);
+int32_t v4h_energy_plan_param_shape(const v4h_energy_plan* plan, int32_t index, int32_t* rows, int32_t* cols);
+size_t v4h_energy_plan_workspace_bytes(const v4h_energy_plan* plan, int32_t B);
+/* d_x (B, dims_in) f32, d_t (B) f32, d_c (B, 1) f32 -> d_out (B, dims_in) f32.  flags: V4H_FWD_REUSE_OPERANDS as above;
+ * V4H_ENERGY_SAME_CONDITION: d_c holds the same values as in the previous call on this workspace - the encoder output and the
+ * decoder's cross-attention terms (functions of the condition only) are reused: the ODE solver calls the network 80 times per
+ * batch with one condition (models/base_model.py:231-242). */
+#define V4H_ENERGY_SAME_CONDITION 4
+int32_t v4h_energy_forward(const v4h_energy_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
+                           float* d_out, void* d_workspace, size_t workspace_bytes, int32_t flags, void* stream);
+
 /* ---- CFM step pieces ------------------------------------------------------------------------------------- */
 /* linear_trajectory + target (models/trajectories.py:5-8, models/base_model.py:214): x_t = (1-t) x0 + t x1, target = x1 - x0 */
 int32_t v4h_cfm_prepare(const float* d_x1, const float* d_x0, const float* d_t, float* d_xt, float* d_target, int32_t B, int64_t per_sample, void* stream);

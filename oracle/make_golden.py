@@ -10,7 +10,7 @@ are absent from this image:
                                             published algorithm ('rk4' = 3/8 rule); this
                                             part is therefore NOT pinned by third-party code.
 
-Then runs the reference classes (nn.vit.ViT, CaloChallengeCFM, CFM._batch_loss,
+Then runs the reference classes (nn.vit.ViT, CaloChallengeCFM and its sibling wrappers, nn.cfm.transformer_cfm.ParallelTransformer, CFM._batch_loss,
 sample_batch, torch.optim.AdamW + clip_grad_norm_ as in BaseExperiment._step) on seeded
 synthetic CaloChallenge-shaped inputs and stores inputs + outputs as small fixtures.
 Weights are not stored: both sides fill them with oracle.vit_cfm_oracle.golden_fill.
@@ -33,6 +33,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 REF = "/root/reference"
 
+from oracle import energy_oracle as E  # noqa: E402
 from oracle import vit_cfm_oracle as O  # noqa: E402
 
 
@@ -277,6 +278,60 @@ def check_branches(cfg):
     assert d < 1e-5
 
 
+def make_energy_case(name, cfg: E.EnergyConfig, B, seed, sample_specs):
+    """Energy-model CFM (configs/model/cfm/cfm_ds2_energy.yaml): the reference's ParallelTransformer inside models.base_model.CFM."""
+    from models.base_model import CFM
+    from nn.cfm.transformer_cfm import ParallelTransformer
+
+    torch.manual_seed(4321)
+    net = ParallelTransformer({"dims_in": cfg.dims_in, "dims_c": cfg.dims_c, "dim_embedding": cfg.dim_embedding, "nhead": cfg.nhead,
+                               "num_encoder_layers": cfg.num_encoder_layers, "num_decoder_layers": cfg.num_decoder_layers,
+                               "dim_feedforward": cfg.dim_feedforward, "dropout": 0.0, "activation": "relu", "embeds": True,
+                               "encode_t_scale": cfg.encode_t_scale, "encode_t_dim": cfg.encode_t_dim})
+    model = CFM(net, "uniform", "linear", {"method": "rk4", "options": {"step_size": 0.05}}, shape=[cfg.dims_in])
+    model.device, model.dtype = torch.device("cpu"), torch.float32
+    ref_names = [k[4:] for k, _ in model.named_parameters()]
+    assert ref_names == list(E.param_shapes(cfg).keys()), (ref_names, list(E.param_shapes(cfg).keys()))
+    fill = E.golden_fill(cfg)
+    sd = model.state_dict()
+    for k, v in fill.items():
+        assert sd["net." + k].shape == v.shape, (k, sd["net." + k].shape, v.shape)
+        sd["net." + k] = v.clone()
+    sd["net.layers.0.weight"], sd["net.layers.0.bias"] = fill["layer.weight"].clone(), fill["layer.bias"].clone()  # the shared tensor's second name
+    model.load_state_dict(sd)
+    model.eval()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, cfg.dims_in), generator=g)
+    c = torch.rand((B, cfg.dims_c), generator=g)
+    t = torch.rand((B, 1), generator=g)
+    out = {"x": x.numpy(), "c": c.numpy(), "t": t.numpy(), "nparams": np.int64(sum(p.numel() for p in model.parameters()))}
+    with torch.no_grad():
+        out["velocity"] = model.forward(x, t, c).numpy()
+        out["t_emb"] = net.time_embed(t).numpy()
+    # loss through the reference's own _batch_loss (t, x0 from the global generator, replayed)
+    torch.manual_seed(seed + 100)
+    loss = model._batch_loss([x.clone(), c])
+    torch.manual_seed(seed + 100)
+    t2 = torch.rand([B, 1])
+    x0 = torch.randn_like(x)
+    with torch.no_grad():
+        v2 = model.forward((1 - t2) * x0 + t2 * x, t2, c)
+        assert torch.allclose(((v2 - (x - x0)) ** 2).mean(), loss, rtol=0, atol=0), "t/x0 replay mismatch"
+    out.update({"loss_t": t2.numpy(), "loss_x0": x0.numpy(), "loss": np.float64(loss.item())})
+    for tag, method, step in sample_specs:
+        model.odeint_kwargs = {"method": method, "options": {"step_size": step}}
+        torch.manual_seed(seed + 200)
+        smp = model.sample_batch(c)
+        torch.manual_seed(seed + 200)
+        x_T = torch.randn((B, cfg.dims_in))
+        out["x_T"] = x_T.numpy()
+        out[f"sample/{tag}"] = smp.numpy()
+        out[f"sample_meta/{tag}"] = np.array([step])
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={loss.item():.6f} |v|={float(np.abs(out['velocity']).max()):.4f} nparams={int(out['nparams'])} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     _install_standins()
     sys.path.insert(0, REF)
@@ -291,6 +346,10 @@ def main():
     make_case("calogan_d2_b3", O.calogan(2), 3, 23, [("rk4_coarse", "rk4", 0.25)], 3, kind="calogan")
     make_case("calohad_d2_b1", O.calohad(2), 1, 24, [("rk4_coarse", "rk4", 0.5)], 2, kind="calohad")
     make_case("lemurs_d2_b2", O.lemurs(2), 2, 25, [("rk4_coarse", "rk4", 0.25)], 0, kind="lemurs")
+    # the energy-model CFM
+    make_energy_case("energy_ds2_b5", E.EnergyConfig(), 5, 31, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)])
+    make_energy_case("energy_small_b3", E.EnergyConfig(dims_in=30, dim_embedding=32, nhead=2, num_encoder_layers=1, num_decoder_layers=2,
+                                                       dim_feedforward=256, encode_t_dim=32), 3, 32, [("rk4_coarse", "rk4", 0.25)])
 
 
 if __name__ == "__main__":

@@ -36,6 +36,11 @@ class V4HConfig(C.Structure):
     ]
 
 
+class V4HEnergyConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("dims_in", "dims_c", "dim_embedding", "nhead", "num_encoder_layers", "num_decoder_layers", "dim_feedforward",
+                                         "encode_t_dim", "mode")]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
 
@@ -52,6 +57,12 @@ SIGNATURES = {
     "v4h_vit_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),
     "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),
+    "v4h_energy_plan_create": (_i32, [C.POINTER(V4HEnergyConfig), _pp]),
+    "v4h_energy_plan_destroy": (None, [_vp]),
+    "v4h_energy_plan_num_params": (_i32, [_vp]),
+    "v4h_energy_plan_param_shape": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "v4h_energy_plan_workspace_bytes": (_sz, [_vp, _i32]),
+    "v4h_energy_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "v4h_cfm_prepare": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
@@ -192,5 +203,37 @@ class Plan:
         try:
             if _lib is not None and getattr(self, "handle", None):
                 _lib.v4h_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+FWD_TRAINING, FWD_REUSE_OPERANDS, ENERGY_SAME_CONDITION = 1, 2, 4  # flag bits of include/vit4hep_hip.h
+
+
+class EnergyPlan:
+    """Host-side plan of the energy-model network (v4h_energy_plan_*)."""
+
+    def __init__(self, dims_in, dims_c, dim_embedding, nhead, num_encoder_layers, num_decoder_layers, dim_feedforward, encode_t_dim, mode="f32"):
+        lib = load()
+        cfg = V4HEnergyConfig(int(dims_in), int(dims_c), int(dim_embedding), int(nhead), int(num_encoder_layers), int(num_decoder_layers),
+                              int(dim_feedforward), int(encode_t_dim), MODES[mode] if isinstance(mode, str) else int(mode))
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib.v4h_energy_plan_create(C.byref(cfg), C.byref(h)), "v4h_energy_plan_create")
+        self.handle = h
+        self.num_params = lib.v4h_energy_plan_num_params(h)
+        self.shapes = []
+        for i in range(self.num_params):
+            r, c = _i32(), _i32()
+            check(lib.v4h_energy_plan_param_shape(h, i, C.byref(r), C.byref(c)), "v4h_energy_plan_param_shape")
+            self.shapes.append((r.value,) if c.value == 0 else (r.value, c.value))
+
+    def workspace_bytes(self, B):
+        return int(load().v4h_energy_plan_workspace_bytes(self.handle, int(B)))
+
+    def __del__(self):
+        try:
+            if _lib is not None and getattr(self, "handle", None):
+                _lib.v4h_energy_plan_destroy(self.handle)
         except Exception:
             pass

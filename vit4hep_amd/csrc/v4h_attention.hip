@@ -456,17 +456,21 @@ template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
 
 // One workgroup per (batch, head): K/V (or Q/dO) are loaded once and every 16-row tile of the lane-side sequence gets a
 // wave.  9 waves when the tile count is a multiple of 9 (ds2: T = 135 -> 9 tiles, no idle wave), else 8 (ds3: 29 tiles).
-template <typename T, int NW> int attn_fwd_launch(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
-  using C = AttnCfg<T, 80>;
+template <typename T, int NW, int DHT = 80> int attn_fwd_launch(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
+  using C = AttnCfg<T, DHT>;
   const size_t lds = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
-  int rc = set_lds(attn_fwd_kernel<T, 80, NW>, lds, "attn_fwd");
+  int rc = set_lds(attn_fwd_kernel<T, DHT, NW>, lds, "attn_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DHT, NW>), dim3(B * H, 1), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
   V4H_CHECK_LAUNCH("attn_fwd");
   return V4H_OK;
 }
 template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
-  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80 = 480/6, every shipped shape-CFM config)", DH);
+  if (DH == 32) {  // energy-model transformer (d_model 128, 4 heads; configs/model/cfm/cfm_ds2_energy.yaml), forward only
+    V4H_CHECK_ARG(Tn <= 64, "attention: head_dim 32 is built for sequences of at most 64 tokens (got %d)", Tn);
+    return attn_fwd_launch<T, 4, 32>(qkv, o, lse, B, Tn, H, DH, s);
+  }
+  V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (80 = 480/6 for every shape-CFM config, 32 forward-only for the energy model)", DH);
   const int ntiles = (Tn + 15) / 16;
   if constexpr (sizeof(T) == 2) {
     static const bool persist = !(getenv("V4H_ATTN_PERSIST") && getenv("V4H_ATTN_PERSIST")[0] == '0');

@@ -1,0 +1,351 @@
+// Energy-model velocity field: the reference's ParallelTransformer (nn/cfm/transformer_cfm.py:12-119) in the
+// configuration every shipped energy model uses (configs/model/cfm/cfm_ds{1,2,3}*_energy.yaml: embeds true, ONE condition token,
+// d_model 128 = 4 heads x 32, 4 + 4 post-norm nn.Transformer layers, feed-forward 512), forward only - it is sampled, 80 network
+// evaluations per batch, right before the shape model (experiments/calochallenge/experiment.py:225-247).
+//
+// What the structure gives away, exactly (not an approximation):
+//  * the memory sequence has ONE token, so every softmax over it is 1: encoder self-attention and decoder cross-attention reduce to
+//    out_proj(v_proj(.)); queries and keys of those attentions never matter.  The encoder is then a per-sample vector chain, and the
+//    cross-attention output of decoder layer l is one vector per sample, added to all tokens;
+//  * memory and cross vectors depend on the condition only, not on (x, t): the ODE solver calls the network with the same condition
+//    for every evaluation of a batch, so they are computed once per batch (V4H_ENERGY_SAME_CONDITION skips them afterwards);
+//  * the head Linear(t_dim + d_model -> ff) on [t | embedding] splits into a per-sample vector (time part + bias) and a token GEMM.
+// Per evaluation that leaves, on (B * dims_in) token rows: 4 x [in_proj GEMM, attention (head_dim 32), out_proj GEMM + residual,
+// LayerNorm x2 fused (+ cross vector), FFN GEMM relu, FFN GEMM + residual, LayerNorm] + embedding + head.
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/vit4hep_hip.h"
+#include "v4h_ops.h"
+
+using namespace v4h;
+
+#define RUN(x)           \
+  do {                   \
+    int rc_ = (x);       \
+    if (rc_) return rc_; \
+  } while (0)
+
+struct v4h_energy_plan {
+  v4h_energy_config cfg;
+  Mode mode;
+  int L, d, e, te, ff, H, ne, nd;
+  std::vector<int> rows, cols;
+  int nparams() const { return (int)rows.size(); }
+  // parameter indices (order of the reference module's named_parameters(), oracle/energy_oracle.py:param_shapes)
+  enum { GFP_W = 0, TE_W, TE_B, XE_W, XE_B, CE_W, CE_B, POS_X, POS_C, HEAD_W, HEAD_B, ENC0 };
+  enum { IN_W = 0, IN_B, OUT_W, OUT_B };                                   // MultiheadAttention
+  enum { E_L1W = 4, E_L1B, E_L2W, E_L2B, E_N1W, E_N1B, E_N2W, E_N2B, E_COUNT };  // encoder layer after self_attn
+  enum { D_CA = 4, D_L1W = 8, D_L1B, D_L2W, D_L2B, D_N1W, D_N1B, D_N2W, D_N2B, D_N3W, D_N3B, D_COUNT };
+  int enc(int i, int k) const { return ENC0 + E_COUNT * i + k; }
+  int enc_norm(int k) const { return ENC0 + E_COUNT * ne + k; }
+  int dec(int i, int k) const { return ENC0 + E_COUNT * ne + 2 + D_COUNT * i + k; }
+  int dec_norm(int k) const { return ENC0 + E_COUNT * ne + 2 + D_COUNT * nd + k; }
+  int out_w() const { return dec_norm(2); }
+  int out_b() const { return dec_norm(3); }
+};
+
+extern "C" int32_t v4h_energy_plan_create(const v4h_energy_config* c, v4h_energy_plan** out) {
+  V4H_CHECK_ARG(c && out, "energy_plan_create: null argument");
+  V4H_CHECK_ARG(c->mode == V4H_MODE_F32 || c->mode == V4H_MODE_BF16, "energy_plan_create: unknown mode %d", c->mode);
+  V4H_CHECK_ARG(c->dims_c == 1, "energy_plan_create: dims_c %d not built (every shipped energy model conditions on one token: the incident energy)", c->dims_c);
+  V4H_CHECK_ARG(c->dims_in >= 1 && c->dims_in <= 64, "energy_plan_create: dims_in %d outside 1..64", c->dims_in);
+  V4H_CHECK_ARG(c->encode_t_dim == c->dim_embedding, "energy_plan_create: embeds=True needs encode_t_dim == dim_embedding (transformer_cfm.py:45,87-89)");
+  V4H_CHECK_ARG(c->dim_embedding % 32 == 0 && c->dim_embedding >= 32 && 2 * c->dim_embedding <= 512, "energy_plan_create: dim_embedding %d must be a multiple of 32, at most 256", c->dim_embedding);
+  V4H_CHECK_ARG(c->nhead > 0 && (2 * c->dim_embedding) % c->nhead == 0, "embed_dim must be divisible by num_heads");
+  V4H_CHECK_ARG(2 * c->dim_embedding / c->nhead == 32, "energy_plan_create: head_dim %d not built (only 32 = 128 / 4)", 2 * c->dim_embedding / c->nhead);
+  V4H_CHECK_ARG(c->dim_feedforward % 64 == 0 && c->dim_feedforward >= 64 && c->dim_feedforward <= 2048, "energy_plan_create: dim_feedforward %d must be a multiple of 64 (<= 2048)", c->dim_feedforward);
+  V4H_CHECK_ARG(c->num_encoder_layers >= 1 && c->num_decoder_layers >= 1, "energy_plan_create: need at least one encoder and one decoder layer");
+  v4h_energy_plan* p = new v4h_energy_plan();
+  p->cfg = *c;
+  p->mode = (Mode)c->mode;
+  p->L = c->dims_in; p->e = c->dim_embedding; p->d = 2 * p->e; p->te = c->encode_t_dim; p->ff = c->dim_feedforward; p->H = c->nhead;
+  p->ne = c->num_encoder_layers; p->nd = c->num_decoder_layers;
+  auto add = [&](int r, int cc) { p->rows.push_back(r); p->cols.push_back(cc); };
+  const int d = p->d, e = p->e, ff = p->ff, te = p->te;
+  add(te / 2, 0); add(te, te); add(te, 0); add(e, 1); add(e, 0); add(2 * e, 1); add(2 * e, 0); add(p->L, e); add(1, 2 * e); add(ff, 3 * e); add(ff, 0);
+  auto mha = [&] { add(3 * d, d); add(3 * d, 0); add(d, d); add(d, 0); };
+  auto ffn_norms = [&](int n) { add(ff, d); add(ff, 0); add(d, ff); add(d, 0); for (int k = 0; k < n; ++k) { add(d, 0); add(d, 0); } };
+  for (int i = 0; i < p->ne; ++i) { mha(); ffn_norms(2); }
+  add(d, 0); add(d, 0);
+  for (int i = 0; i < p->nd; ++i) { mha(); mha(); ffn_norms(3); }
+  add(d, 0); add(d, 0);
+  add(1, ff); add(1, 0);
+  *out = p;
+  return V4H_OK;
+}
+extern "C" void v4h_energy_plan_destroy(v4h_energy_plan* p) { delete p; }
+extern "C" int32_t v4h_energy_plan_num_params(const v4h_energy_plan* p) { return p ? p->nparams() : 0; }
+extern "C" int32_t v4h_energy_plan_param_shape(const v4h_energy_plan* p, int32_t i, int32_t* r, int32_t* c) {
+  V4H_CHECK_ARG(p && i >= 0 && i < p->nparams(), "energy param_shape: bad index %d", i);
+  *r = p->rows[i];
+  *c = p->cols[i];
+  return V4H_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ workspace
+namespace {
+struct EWS {
+  std::vector<char*> wop;  // mode-typed operand copies of the GEMM weights (bf16 mode only)
+  float *ones, *temb, *hv, *h, *m, *cv, *lse;
+  char *gfp, *tembT, *hT, *qkv, *o, *f, *z, *mT, *mv, *mo, *mf, *cvt;
+};
+bool is_gemm_weight(const v4h_energy_plan& p, int i) {
+  if (p.cols[i] == 0) return false;
+  return !(i == v4h_energy_plan::XE_W || i == v4h_energy_plan::CE_W || i == v4h_energy_plan::POS_X || i == v4h_energy_plan::POS_C || i == p.out_w());
+}
+size_t elayout(const v4h_energy_plan& p, int B, char* base, EWS& w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* r = base ? base + off : nullptr;
+    off += (bytes + 255) / 256 * 256;
+    return r;
+  };
+  const size_t es = esize(p.mode), BL = (size_t)B * p.L, d = p.d, ff = p.ff, te = p.te;
+  w.wop.assign(p.nparams(), nullptr);
+  if (p.mode == MODE_BF16)
+    for (int i = 0; i < p.nparams(); ++i)
+      if (is_gemm_weight(p, i)) w.wop[i] = take((size_t)p.rows[i] * p.cols[i] * es);
+  w.ones = (float*)take(d * 4);
+  w.gfp = take((size_t)B * te * es);
+  w.temb = (float*)take((size_t)B * te * 4);
+  w.tembT = take((size_t)B * te * es);
+  w.hv = (float*)take((size_t)B * ff * 4);
+  w.h = (float*)take(BL * d * 4);
+  w.hT = take(BL * d * es);
+  w.qkv = take(BL * 3 * d * es);
+  w.o = take(BL * d * es);
+  w.f = take(BL * ff * es);
+  w.z = take(BL * ff * es);
+  w.lse = (float*)take((size_t)B * p.H * p.L * 4);
+  w.m = (float*)take((size_t)B * d * 4);
+  w.mT = take((size_t)B * d * es);
+  w.mv = take((size_t)B * d * es);
+  w.mf = take((size_t)B * ff * es);
+  w.cvt = take((size_t)B * d * es);
+  w.cv = (float*)take((size_t)p.nd * B * d * 4);
+  return off;
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// GaussianFourierProjection (transformer_cfm.py:153-165): [sin(t W 2 pi) | cos(t W 2 pi)], same f32 operation order; also refreshes the ones vector
+template <typename T> __global__ void gfp_kernel(const float* __restrict__ t, const float* __restrict__ W, T* __restrict__ out, float* __restrict__ ones, int B, int te, int d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < d) ones[idx] = 1.0f;
+  if (idx >= B * te) return;
+  const int b = idx / te, j = idx % te, half = te / 2;
+  float pr = t[b] * W[j < half ? j : j - half];
+  pr = pr * 2.0f;
+  pr = pr * 3.14159265358979323846f;
+  out[idx] = (T)(j < half ? sinf(pr) : cosf(pr));
+}
+// compute_embedding(x, dims_in, t): token (b, n) = [time embedding | x * w + b + pos[n]]   transformer_cfm.py:84-90
+template <typename T> __global__ void energy_embed_kernel(const float* __restrict__ x, const float* __restrict__ temb, const float* __restrict__ wx, const float* __restrict__ bx,
+                                                          const float* __restrict__ pos, float* __restrict__ h, T* __restrict__ hT, int B, int L, int e, int te) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d = te + e;
+  if (idx >= (long)B * L * d) return;
+  const int j = (int)(idx % d);
+  const long tok = idx / d;
+  const int b = (int)(tok / L), n = (int)(tok % L);
+  const float v = j < te ? temb[(long)b * te + j] : x[tok] * wx[j - te] + bx[j - te] + pos[(long)n * e + j - te];
+  h[idx] = v;
+  hT[idx] = (T)v;
+}
+// compute_embedding(condition, 1): c * w + b + pos_c[0]   transformer_cfm.py:91-94
+template <typename T> __global__ void cond_embed_kernel(const float* __restrict__ c, const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ posc,
+                                                        float* __restrict__ m, T* __restrict__ mT, int B, int d) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * d) return;
+  const int j = idx % d;
+  const float v = c[idx / d] * wc[j] + bc[j] + posc[j];
+  m[idx] = v;
+  mT[idx] = (T)v;
+}
+// Up to two chained affine LayerNorms (eps 1e-5) over rows of d <= 512 (d % 64 == 0), each optionally preceded by adding a per-sample
+// vector (the cross-attention output of a one-token memory); in place on the f32 rows, plus a mode-typed copy for the next GEMM.
+struct LnStage { const float* add; int ld_add; const float* gamma; const float* beta; };
+template <typename T> __global__ __launch_bounds__(256) void ln_affine_kernel(float* __restrict__ x, T* __restrict__ xT, LnStage s0, LnStage s1, int nstage, int rows, int rows_per_sample, int d) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int b = row / rows_per_sample;
+  float v[8];
+  const int nv = d / 64;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = k < nv ? x[(long)row * d + lane + 64 * k] : 0.f;
+  for (int st = 0; st < nstage; ++st) {
+    const LnStage& s = st == 0 ? s0 : s1;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv) {
+        if (s.add) v[k] += s.add[(long)b * s.ld_add + lane + 64 * k];
+        sum += v[k];
+      }
+    const float mu = wave_sum(sum) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv) q += (v[k] - mu) * (v[k] - mu);
+    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv) v[k] = (v[k] - mu) * rs * s.gamma[lane + 64 * k] + s.beta[lane + 64 * k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < nv) {
+      x[(long)row * d + lane + 64 * k] = v[k];
+      xT[(long)row * d + lane + 64 * k] = (T)v[k];
+    }
+}
+// head, last Linear(ff -> 1): out[row] = z[row] . w + b   transformer_cfm.py:66-70
+template <typename T> __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int rows, int ff) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int j = lane * 4; j < ff; j += 256) {
+    const f32x4 zv = load4(z + (long)row * ff + j);
+    const f32x4 wv = load4(w + j);
+    s += zv[0] * wv[0] + zv[1] * wv[1] + zv[2] * wv[2] + zv[3] * wv[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s + bias[0];
+}
+
+GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int J, int K) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = P; a.ldp = ldp; a.Q = Q; a.ldq = ldq; a.I = I; a.J = J; a.K = K;
+  return a;
+}
+template <typename F> int by_mode(Mode m, F&& f) { return m == MODE_BF16 ? f((bf16*)nullptr) : f((float*)nullptr); }
+}  // namespace
+
+extern "C" size_t v4h_energy_plan_workspace_bytes(const v4h_energy_plan* p, int32_t B) {
+  if (!p || B <= 0) return 0;
+  EWS w;
+  return elayout(*p, B, nullptr, w);
+}
+
+extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const void* const* params, const float* x, const float* t, const float* cnd, float* out,
+                                      void* ws, size_t ws_bytes, int32_t flags, void* stream) {
+  V4H_CHECK_ARG(p != nullptr, "energy_forward: null plan");
+  V4H_CHECK_ARG(B > 0, "energy_forward: empty batch (B=%d)", B);
+  V4H_CHECK_ARG(params && ws && x && t && cnd && out, "energy_forward: null argument");
+  V4H_CHECK_ARG(((uintptr_t)ws % 256) == 0, "energy_forward: workspace must be 256-byte aligned");
+  V4H_CHECK_ARG((flags & ~(V4H_FWD_REUSE_OPERANDS | V4H_ENERGY_SAME_CONDITION)) == 0, "energy_forward: unknown flag bits 0x%x (the network is forward-only)", flags);
+  V4H_CHECK_ARG(ws_bytes >= v4h_energy_plan_workspace_bytes(p, B), "energy_forward: workspace too small (%zu < %zu bytes)", ws_bytes, v4h_energy_plan_workspace_bytes(p, B));
+  for (int i = 0; i < p->nparams(); ++i) V4H_CHECK_ARG(params[i] != nullptr && ((uintptr_t)params[i] % 16) == 0, "energy_forward: parameter %d null or not 16-byte aligned", i);
+  using PL = v4h_energy_plan;
+  const Mode m = p->mode;
+  hipStream_t s = (hipStream_t)stream;
+  EWS w;
+  elayout(*p, B, (char*)ws, w);
+  const int L = p->L, d = p->d, e = p->e, te = p->te, ff = p->ff, H = p->H, BL = B * L;
+  auto pf = [&](int i) { return (const float*)params[i]; };
+  auto W = [&](int i) -> const char* { return w.wop[i] ? w.wop[i] : (const char*)params[i]; };  // GEMM-operand view of a weight
+  const size_t es = esize(m);
+  const bool reuse = (flags & V4H_FWD_REUSE_OPERANDS) != 0, same_c = (flags & V4H_ENERGY_SAME_CONDITION) != 0;
+
+  // 0. operand copies of the GEMM weights (bf16 mode)
+  if (m == MODE_BF16 && !reuse) {
+    std::vector<CastPadItem> items;
+    for (int i = 0; i < p->nparams(); ++i)
+      if (w.wop[i]) items.push_back(CastPadItem{pf(i), w.wop[i], p->rows[i], p->cols[i], p->rows[i], p->cols[i], 0});
+    RUN(cast_pad_many(m, items.data(), (int)items.size(), s));
+  }
+  auto ln = [&](float* xr, void* xT, LnStage s0, LnStage s1, int nstage, int rows, int rps) -> int {
+    const dim3 grid((rows + 3) / 4);
+    if (m == MODE_BF16) hipLaunchKernelGGL(ln_affine_kernel<bf16>, grid, dim3(256), 0, s, xr, (bf16*)xT, s0, s1, nstage, rows, rps, d);
+    else hipLaunchKernelGGL(ln_affine_kernel<float>, grid, dim3(256), 0, s, xr, (float*)xT, s0, s1, nstage, rows, rps, d);
+    V4H_CHECK_LAUNCH("ln_affine");
+    return V4H_OK;
+  };
+  auto stage = [&](const float* add, int ld, int gi) { return LnStage{add, ld, pf(gi), pf(gi + 1)}; };
+  // y = resid + (P Q^T + bias) in place on the f32 rows: EPI_GATE_RESID with a gate of ones
+  auto gemm_resid = [&](const void* P, int ldp, const char* Q, int ldq, const float* bias, float* rows_io, int I, int J, int K, int rps) -> int {
+    GemmArgs a = gargs(P, ldp, Q, ldq, I, J, K);
+    a.e.out = rows_io; a.e.ldo = J; a.e.bias = bias; a.e.rowvec = w.ones; a.e.ld_rowvec = 0; a.e.T = rps; a.e.resid = rows_io; a.e.ld_resid = J;
+    return gemm_fwd(m, EPI_GATE_RESID, a, s);
+  };
+  auto gemm_to = [&](int epi, const void* P, int ldp, const char* Q, int ldq, const float* bias, void* o, int ldo, int I, int J, int K) -> int {
+    GemmArgs a = gargs(P, ldp, Q, ldq, I, J, K);
+    a.e.out = o; a.e.ldo = ldo; a.e.bias = bias;
+    return gemm_fwd(m, epi, a, s);
+  };
+
+  // 1. time embedding (per evaluation)   transformer_cfm.py:39-42
+  {
+    const int n = B * te > d ? B * te : d;
+    if (m == MODE_BF16) hipLaunchKernelGGL(gfp_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t, pf(PL::GFP_W), (bf16*)w.gfp, w.ones, B, te, d);
+    else hipLaunchKernelGGL(gfp_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t, pf(PL::GFP_W), (float*)w.gfp, w.ones, B, te, d);
+    V4H_CHECK_LAUNCH("gfp");
+    RUN(gemm_to(EPI_STORE_F32, w.gfp, te, W(PL::TE_W), te, pf(PL::TE_B), w.temb, te, B, te, te));
+    RUN(gemm_to(EPI_STORE, w.gfp, te, W(PL::TE_W), te, pf(PL::TE_B), w.tembT, te, B, te, te));
+    // head, time part: hv[b] = W_head[:, :te] temb[b] + b_head   (the t columns of Linear(3e -> ff) on [t | embedding])
+    RUN(gemm_to(EPI_STORE_F32, w.tembT, te, W(PL::HEAD_W), 3 * e, pf(PL::HEAD_B), w.hv, ff, B, ff, te));
+  }
+
+  // 2. encoder on the single condition token + the decoder layers' cross-attention vectors (per condition batch)
+  if (!same_c) {
+    by_mode(m, [&](auto* tag) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      hipLaunchKernelGGL(cond_embed_kernel<T>, dim3((B * d + 255) / 256), dim3(256), 0, s, cnd, pf(PL::CE_W), pf(PL::CE_B), pf(PL::POS_C), w.m, (T*)w.mT, B, d);
+      return 0;
+    });
+    V4H_CHECK_LAUNCH("cond_embed");
+    for (int i = 0; i < p->ne; ++i) {
+      // self-attention over ONE token = out_proj(v_proj(m)): softmax of a single score is 1
+      RUN(gemm_to(EPI_STORE, w.mT, d, W(p->enc(i, PL::IN_W)) + (size_t)2 * d * d * es, d, pf(p->enc(i, PL::IN_B)) + 2 * d, w.mv, d, B, d, d));
+      RUN(gemm_resid(w.mv, d, W(p->enc(i, PL::OUT_W)), d, pf(p->enc(i, PL::OUT_B)), w.m, B, d, d, 1));
+      RUN(ln(w.m, w.mT, stage(nullptr, 0, p->enc(i, PL::E_N1W)), LnStage{}, 1, B, 1));
+      RUN(gemm_to(EPI_RELU, w.mT, d, W(p->enc(i, PL::E_L1W)), d, pf(p->enc(i, PL::E_L1B)), w.mf, ff, B, ff, d));
+      RUN(gemm_resid(w.mf, ff, W(p->enc(i, PL::E_L2W)), ff, pf(p->enc(i, PL::E_L2B)), w.m, B, d, ff, 1));
+      const bool last = i == p->ne - 1;  // the stack's final LayerNorm rides on the last layer's
+      RUN(ln(w.m, w.mT, stage(nullptr, 0, p->enc(i, PL::E_N2W)), last ? stage(nullptr, 0, p->enc_norm(0)) : LnStage{}, last ? 2 : 1, B, 1));
+    }
+    for (int i = 0; i < p->nd; ++i) {  // cross-attention of decoder layer i over the one memory token
+      RUN(gemm_to(EPI_STORE, w.mT, d, W(p->dec(i, PL::D_CA + PL::IN_W)) + (size_t)2 * d * d * es, d, pf(p->dec(i, PL::D_CA + PL::IN_B)) + 2 * d, w.cvt, d, B, d, d));
+      RUN(gemm_to(EPI_STORE_F32, w.cvt, d, W(p->dec(i, PL::D_CA + PL::OUT_W)), d, pf(p->dec(i, PL::D_CA + PL::OUT_B)), w.cv + (size_t)i * B * d, d, B, d, d));
+    }
+  }
+
+  // 3. target embedding   transformer_cfm.py:84-90
+  by_mode(m, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    const long n = (long)BL * d;
+    hipLaunchKernelGGL(energy_embed_kernel<T>, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x, w.temb, pf(PL::XE_W), pf(PL::XE_B), pf(PL::POS_X), w.h, (T*)w.hT, B, L, e, te);
+    return 0;
+  });
+  V4H_CHECK_LAUNCH("energy_embed");
+
+  // 4. decoder stack (post-norm)
+  for (int i = 0; i < p->nd; ++i) {
+    RUN(gemm_to(EPI_STORE, w.hT, d, W(p->dec(i, PL::IN_W)), d, pf(p->dec(i, PL::IN_B)), w.qkv, 3 * d, BL, 3 * d, d));
+    RUN(attention_fwd(m, w.qkv, w.o, nullptr, B, L, H, d / H, s));
+    RUN(gemm_resid(w.o, d, W(p->dec(i, PL::OUT_W)), d, pf(p->dec(i, PL::OUT_B)), w.h, BL, d, d, L));
+    // norm1, then x + cross-attention vector, norm2 - one pass
+    RUN(ln(w.h, w.hT, stage(nullptr, 0, p->dec(i, PL::D_N1W)), stage(w.cv + (size_t)i * B * d, d, p->dec(i, PL::D_N2W)), 2, BL, L));
+    RUN(gemm_to(EPI_RELU, w.hT, d, W(p->dec(i, PL::D_L1W)), d, pf(p->dec(i, PL::D_L1B)), w.f, ff, BL, ff, d));
+    RUN(gemm_resid(w.f, ff, W(p->dec(i, PL::D_L2W)), ff, pf(p->dec(i, PL::D_L2B)), w.h, BL, d, ff, L));
+    const bool last = i == p->nd - 1;
+    RUN(ln(w.h, w.hT, stage(nullptr, 0, p->dec(i, PL::D_N3W)), last ? stage(nullptr, 0, p->dec_norm(0)) : LnStage{}, last ? 2 : 1, BL, L));
+  }
+
+  // 5. head: silu(W_head[:, te:] h + hv[b]) . w_out + b_out   transformer_cfm.py:114-119
+  {
+    GemmArgs a = gargs(w.hT, d, W(PL::HEAD_W) + (size_t)te * es, 3 * e, BL, ff, d);
+    a.e.out = w.z; a.e.ldo = ff; a.e.rowvec = w.hv; a.e.ld_rowvec = ff; a.e.T = L;
+    RUN(gemm_fwd(m, EPI_ROWADD_SILU, a, s));
+    const dim3 grid((BL + 3) / 4);
+    if (m == MODE_BF16) hipLaunchKernelGGL(rowdot_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)w.z, pf(p->out_w()), pf(p->out_b()), out, BL, ff);
+    else hipLaunchKernelGGL(rowdot_kernel<float>, grid, dim3(256), 0, s, (const float*)w.z, pf(p->out_w()), pf(p->out_b()), out, BL, ff);
+    V4H_CHECK_LAUNCH("rowdot");
+  }
+  return V4H_OK;
+}

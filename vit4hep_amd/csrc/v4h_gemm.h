@@ -34,6 +34,8 @@ enum : int {
   EPI_ACCUM_F32,      // out(f32)[i][j] += acc
   EPI_UNPATCH,        // voxel scatter: out(f32)[b, voxel(n, f=j)] = acc + bias[j]  (final linear + from_patches)
   EPI_SLAB_F32,       // split-K partial: out(f32)[z][i][j] = acc (plain stores; summed afterwards by slab_reduce)
+  EPI_RELU,           // out(TO) = max(acc + bias, 0)                               (nn.Transformer feed-forward, energy model)
+  EPI_ROWADD_SILU,    // out(TO) = silu(acc + bias + rowvec[b(i)][j])               (energy-model head: per-sample time term)
 };
 
 struct PatchGeom {  // CaloChallengeCFM.to_patches / from_patches  (calochallenge_cfm/model.py:40-60), C = 1
@@ -117,6 +119,8 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       if (e.resid) o.a = load8(e.resid + (size_t)i * e.ld_resid + j);
     } else if constexpr (EPI == EPI_EMBED) {
       o.a = load8(e.rowvec + (size_t)(i % e.T) * e.ld_rowvec + j);
+    } else if constexpr (EPI == EPI_ROWADD_SILU) {
+      o.a = load8(e.rowvec + (size_t)(i / e.T) * e.ld_rowvec + j);
     } else if constexpr (EPI == EPI_GATE_RESID) {
       o.a = load8(e.rowvec + (size_t)(i / e.T) * e.ld_rowvec + j);
       o.b = load8(e.resid + (size_t)i * e.ld_resid + j);
@@ -140,6 +144,14 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       if (e.out2) store8(reinterpret_cast<float*>(e.out2) + (size_t)i * e.ldo2 + j, v);
 #pragma unroll
       for (int r = 0; r < 8; ++r) v.v[r] = silu_f(v.v[r]);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] = fmaxf(v.v[r], 0.0f);
+      store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
+    } else if constexpr (EPI == EPI_ROWADD_SILU) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v.v[r] = silu_f(v.v[r] + o.a.v[r]);
       store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, v);
     } else if constexpr (EPI == EPI_COND_SUM) {
       if (e.resid) v = add8(v, o.a);

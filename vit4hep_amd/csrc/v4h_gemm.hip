@@ -95,6 +95,8 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if constexpr (sizeof(T) == 2) { if (big_fwd(a)) return run_big<T, T, false, EPI_GELU>(a, s, "gemm_fwd/gelu/big"); }
       return run<T, T, false, false, 128, 160, EPI_GELU>(a, 1, s, "gemm_fwd/gelu");
     case EPI_UNPATCH: return run<T, T, false, false, 128, 96, EPI_UNPATCH>(a, 1, s, "gemm_fwd/unpatch");
+    case EPI_RELU: return run<T, T, false, false, 128, 160, EPI_RELU>(a, 1, s, "gemm_fwd/relu");
+    case EPI_ROWADD_SILU: return run<T, T, false, false, 128, 160, EPI_ROWADD_SILU>(a, 1, s, "gemm_fwd/rowadd_silu");
   }
   v4h_set_error("gemm_fwd: epilogue %d not built", epi);
   return V4H_ERR_UNSUPPORTED;

@@ -1,0 +1,136 @@
+"""MI355X host mirror of the reference's ``nn.cfm.transformer_cfm`` (ParallelTransformer), the ENERGY-model velocity field
+(reference nn/cfm/transformer_cfm.py:12-119; configs/model/cfm/cfm_ds{1,2,3}*_energy.yaml).
+
+Same constructor (``ParallelTransformer(param)`` with the defaults of transformer_cfm.py:21-37), same sub-module names, state-dict keys
+and initialisation order (the containers are the very torch classes the reference uses: ``nn.Transformer``, ``nn.Linear``,
+``nn.Embedding``), so checkpoints of the reference load unchanged.  ``forward`` runs in libvit4hep_hip.so and is **inference only**:
+the reference samples this network (80 evaluations per batch, experiments/calochallenge/experiment.py:225-247); training it stays
+with the reference's own module.  There is no PyTorch fallback: what the HIP path does not implement raises.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+
+_DEFAULTS = {  # transformer_cfm.py:22-35
+    "dims_in": 46,
+    "dims_c": 1,
+    "dim_embedding": 180,
+    "nhead": 4,
+    "num_encoder_layers": 2,
+    "num_decoder_layers": 4,
+    "dim_feedforward": 256,
+    "dropout": 0.0,
+    "activation": "relu",
+    "embeds": False,
+    "encode_t_scale": 30,
+    "encode_t_dim": 64,
+}
+
+
+class GaussianFourierProjection(nn.Module):
+    """Parameter container: fixed random frequencies W (reference transformer_cfm.py:153-165)."""
+
+    def __init__(self, embed_dim, scale=30.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embed_dim // 2) * scale, requires_grad=False)
+
+
+class ParallelTransformer(nn.Module):
+    def __init__(self, param):
+        super().__init__()
+        for k, default in _DEFAULTS.items():
+            setattr(self, k, param[k] if k in param else default)
+        self.amd_mode = os.environ.get("VIT4HEP_AMD_MODE") or (param["amd_mode"] if "amd_mode" in param else "f32")
+        if self.amd_mode not in _lib.MODES:
+            raise ValueError(f"amd_mode must be one of {sorted(_lib.MODES)}, got {self.amd_mode!r}")
+        if not self.embeds:
+            raise NotImplementedError("vit4hep_amd: ParallelTransformer with embeds=False (one-hot embedding) is not used by any shipped energy model")
+        if float(self.dropout) != 0.0 or self.activation != "relu":
+            raise NotImplementedError("vit4hep_amd: dropout > 0 / activations other than relu are not on the energy-model path")
+        # same construction order as the reference -> same parameters from the same seed
+        self.time_embed = nn.Sequential(GaussianFourierProjection(embed_dim=self.encode_t_dim, scale=self.encode_t_scale), nn.Linear(self.encode_t_dim, self.encode_t_dim))
+        self.d_model = 2 * self.dim_embedding
+        self.x_embed = nn.Linear(1, self.dim_embedding)
+        self.c_embed = nn.Linear(1, 2 * self.dim_embedding)
+        self.pos_embed_x = nn.Embedding(self.dims_in, self.dim_embedding)
+        self.pos_embed_c = nn.Embedding(self.dims_c, 2 * self.dim_embedding)
+        self.layer = nn.Linear(3 * self.dim_embedding, self.dim_feedforward)
+        self.transformer = nn.Transformer(d_model=self.d_model, nhead=self.nhead, num_encoder_layers=self.num_encoder_layers,
+                                          num_decoder_layers=self.num_decoder_layers, dim_feedforward=self.dim_feedforward, dropout=self.dropout,
+                                          activation=self.activation, batch_first=True)
+        self.layers = nn.Sequential(self.layer, nn.SiLU(), nn.Linear(self.dim_feedforward, 1))
+        self._plan = None
+        self._ws = {}
+        self._sig = None       # operand copies in the workspace belong to these parameter values
+        self._last_c = None    # (tensor object, version, workspace pointer) of the condition whose encoder output the workspace holds
+
+    # ------------------------------------------------------------------ HIP plumbing
+    def parameter_list(self):
+        """Tensors in named_parameters() order = the order the C ABI expects (include/vit4hep_hip.h)."""
+        return [p for _, p in self.named_parameters()]
+
+    def _get_plan(self):
+        if self._plan is None:
+            self._plan = _lib.EnergyPlan(self.dims_in, self.dims_c, self.dim_embedding, self.nhead, self.num_encoder_layers, self.num_decoder_layers,
+                                         self.dim_feedforward, self.encode_t_dim, self.amd_mode)
+            got = [tuple(p.shape) for p in self.parameter_list()]
+            if got != self._plan.shapes:
+                raise RuntimeError(f"parameter inventory differs from the library's: {got} vs {self._plan.shapes}")
+        return self._plan
+
+    def _workspace(self, B, device):
+        key = (int(B), str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws = {key: torch.empty(self._get_plan().workspace_bytes(B), dtype=torch.uint8, device=device)}
+            self._sig = self._last_c = None
+            ws = self._ws[key]
+        return ws
+
+    def forward(self, x, t, condition=None):
+        """x (B, dims_in), t (B, 1), condition (B, 1) -> velocity (B, dims_in)   (reference transformer_cfm.py:101-119)"""
+        if condition is None:
+            raise NotImplementedError("vit4hep_amd: the unconditional decoder-only call of ParallelTransformer is not on the energy-model path")
+        params = self.parameter_list()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            raise NotImplementedError("vit4hep_amd: ParallelTransformer runs forward-only in the HIP library (sampling under no_grad / inference_mode); "
+                                      "train the energy model with the reference's own module")
+        cond_obj = condition
+        x = _lib.require_cuda(x, "x")
+        c = _lib.require_cuda(condition, "condition")
+        t = _lib.require_cuda(t, "t").reshape(-1)
+        B = x.shape[0]
+        if tuple(x.shape) != (B, int(self.dims_in)) or t.numel() != B or tuple(c.shape) != (B, int(self.dims_c)):
+            raise RuntimeError(f"bad shapes: x {tuple(x.shape)}, t {tuple(t.shape)}, condition {tuple(c.shape)} for dims_in={self.dims_in}, dims_c={self.dims_c}")
+        for p in params:
+            if not p.is_cuda or p.dtype != torch.float32:
+                raise RuntimeError("vit4hep_amd: parameters must be float32 tensors on the MI355X device (model.to(device, torch.float32))")
+        plan = self._get_plan()
+        ws = self._workspace(B, x.device)
+        flags = 0
+        try:
+            cver = cond_obj._version
+        except RuntimeError:  # a tensor created under inference_mode has no version counter: its content cannot be vouched for
+            cver = None
+        sig = (ws.data_ptr(), tuple((p.data_ptr(), p._version) for p in params))
+        if self._sig == sig:
+            flags |= _lib.FWD_REUSE_OPERANDS
+            # Same condition only if it is the very same tensor OBJECT, unmodified: a new batch's tensor may well live at the old address.
+            if (cver is not None and self._last_c is not None and self._last_c[0] is cond_obj and self._last_c[1] == cver
+                    and self._last_c[2] == ws.data_ptr()):
+                flags |= _lib.ENERGY_SAME_CONDITION
+        self._sig = sig
+        self._last_c = (cond_obj, cver, ws.data_ptr())
+        out = torch.empty_like(x)
+        _lib.check(
+            _lib.load().v4h_energy_forward(plan.handle, B, _lib.pointer_table([p.detach() for p in params]), _lib.ptr(x), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out),
+                                           _lib.ptr(ws), ws.numel(), flags, _lib.stream_ptr(x.device)),
+            "v4h_energy_forward",
+        )
+        return out
