@@ -207,8 +207,13 @@ def test_dropin_aliases_reference_module_paths():
         assert mod.CaloChallengeCFM_DS1.__module__.startswith("vit4hep_amd")  # configs/model/cfm/cfm_ds1_photons.yaml:1
         for path, cls in (("experiments.calogan.model", "CaloGANCFM"), ("experiments.calohadronic.model", "CaloHadCFM"), ("experiments.lemurs.model", "LEMURSCFM")):
             assert getattr(importlib.import_module(path), cls).__module__.startswith("vit4hep_amd")  # configs/model/cfm_{calogan,calohad,lemurs}/*.yaml:1
+        assert "nn.cfm.transformer_cfm" not in sys.modules or not sys.modules["nn.cfm.transformer_cfm"].__name__.startswith("vit4hep_amd")
+        dropin.uninstall()
+        dropin.install(energy_sampler=True)  # opt-in: the forward-only energy-model network
+        assert importlib.import_module("nn.cfm.transformer_cfm").ParallelTransformer.__module__.startswith("vit4hep_amd")
     finally:
         dropin.uninstall()
+        sys.modules.pop("nn.cfm", None)
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v

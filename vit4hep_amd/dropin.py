@@ -23,11 +23,15 @@ ALIASES = {
     "experiments.calohadronic.model": "vit4hep_amd.experiments.calohadronic.model",
     "experiments.lemurs.model": "vit4hep_amd.experiments.lemurs.model",
 }
+# Opt-in: the energy-model network runs FORWARD ONLY in the HIP library (it is sampled, never trained, inside a shape-model run:
+# experiments/calochallenge/experiment.py:225-247, 323-342).  Alias it in processes that only sample; a process that trains an
+# energy model (`model_type: energy`) must keep the reference's own module.
+ENERGY_ALIASES = {"nn.cfm.transformer_cfm": "vit4hep_amd.nn.cfm.transformer_cfm"}
 _installed = []
 
 
-def install():
-    for ref_name, ours in ALIASES.items():
+def install(energy_sampler=False):
+    for ref_name, ours in {**ALIASES, **(ENERGY_ALIASES if energy_sampler else {})}.items():
         parts = ref_name.split(".")
         for i in range(1, len(parts)):  # parent packages: keep the reference's if importable, else a namespace stub
             pkg = ".".join(parts[:i])

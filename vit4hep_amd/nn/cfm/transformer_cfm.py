@@ -66,11 +66,24 @@ class ParallelTransformer(nn.Module):
                                           activation=self.activation, batch_first=True)
         self.layers = nn.Sequential(self.layer, nn.SiLU(), nn.Linear(self.dim_feedforward, 1))
         self._plan = None
+        self._params, self._params_ok, self._ptr_table = None, False, None
         self._ws = {}
         self._sig = None       # operand copies in the workspace belong to these parameter values
         self._last_c = None    # (tensor object, version, workspace pointer) of the condition whose encoder output the workspace holds
 
     # ------------------------------------------------------------------ HIP plumbing
+    def _cache_params(self):
+        self._params = self.parameter_list()
+        return self._params
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): parameter storage changes
+        self._params, self._params_ok, self._sig, self._last_c = None, False, None, None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._params, self._params_ok, self._sig, self._last_c = None, False, None, None
+        return super().load_state_dict(*args, **kwargs)
+
     def parameter_list(self):
         """Tensors in named_parameters() order = the order the C ABI expects (include/vit4hep_hip.h)."""
         return [p for _, p in self.named_parameters()]
@@ -97,7 +110,7 @@ class ParallelTransformer(nn.Module):
         """x (B, dims_in), t (B, 1), condition (B, 1) -> velocity (B, dims_in)   (reference transformer_cfm.py:101-119)"""
         if condition is None:
             raise NotImplementedError("vit4hep_amd: the unconditional decoder-only call of ParallelTransformer is not on the energy-model path")
-        params = self.parameter_list()
+        params = self._params if self._params is not None else self._cache_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             raise NotImplementedError("vit4hep_amd: ParallelTransformer runs forward-only in the HIP library (sampling under no_grad / inference_mode); "
                                       "train the energy model with the reference's own module")
@@ -108,9 +121,12 @@ class ParallelTransformer(nn.Module):
         B = x.shape[0]
         if tuple(x.shape) != (B, int(self.dims_in)) or t.numel() != B or tuple(c.shape) != (B, int(self.dims_c)):
             raise RuntimeError(f"bad shapes: x {tuple(x.shape)}, t {tuple(t.shape)}, condition {tuple(c.shape)} for dims_in={self.dims_in}, dims_c={self.dims_c}")
-        for p in params:
-            if not p.is_cuda or p.dtype != torch.float32:
-                raise RuntimeError("vit4hep_amd: parameters must be float32 tensors on the MI355X device (model.to(device, torch.float32))")
+        if not self._params_ok:
+            for p in params:
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("vit4hep_amd: parameters must be float32 tensors on the MI355X device (model.to(device, torch.float32))")
+            self._ptr_table = _lib.pointer_table([p.detach() for p in params])  # storage pointers only change through _apply / load_state_dict
+            self._params_ok = True
         plan = self._get_plan()
         ws = self._workspace(B, x.device)
         flags = 0
@@ -118,7 +134,7 @@ class ParallelTransformer(nn.Module):
             cver = cond_obj._version
         except RuntimeError:  # a tensor created under inference_mode has no version counter: its content cannot be vouched for
             cver = None
-        sig = (ws.data_ptr(), tuple((p.data_ptr(), p._version) for p in params))
+        sig = (ws.data_ptr(), sum(p._version for p in params))  # version counters only grow: equal sum <=> no parameter written in place
         if self._sig == sig:
             flags |= _lib.FWD_REUSE_OPERANDS
             # Same condition only if it is the very same tensor OBJECT, unmodified: a new batch's tensor may well live at the old address.
@@ -129,7 +145,7 @@ class ParallelTransformer(nn.Module):
         self._last_c = (cond_obj, cver, ws.data_ptr())
         out = torch.empty_like(x)
         _lib.check(
-            _lib.load().v4h_energy_forward(plan.handle, B, _lib.pointer_table([p.detach() for p in params]), _lib.ptr(x), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out),
+            _lib.load().v4h_energy_forward(plan.handle, B, self._ptr_table, _lib.ptr(x), _lib.ptr(t), _lib.ptr(c), _lib.ptr(out),
                                            _lib.ptr(ws), ws.numel(), flags, _lib.stream_ptr(x.device)),
             "v4h_energy_forward",
         )
