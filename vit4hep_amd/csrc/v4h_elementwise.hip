@@ -24,6 +24,12 @@ template <typename T> __global__ void cast_pad_kernel(const CastPadTable tb) {
   const long total = (long)it.Rp * it.Cp;
   T* dst = reinterpret_cast<T*>(it.dst);
   float* dstf = reinterpret_cast<float*>(it.dst);
+  if (it.R == it.Rp && it.C == it.Cp && !it.dst_f32 && (total & 3) == 0) {  // plain cast (almost all weights): no index arithmetic, 16-byte loads
+    for (long idx = (long)(blockIdx.x - tb.first_block[e]) * blockDim.x * 4 + threadIdx.x * 4; idx < total;
+         idx += (long)(tb.first_block[e + 1] - tb.first_block[e]) * blockDim.x * 4)
+      store4(dst + idx, load4(it.src + idx));
+    return;
+  }
   for (long idx = (long)(blockIdx.x - tb.first_block[e]) * blockDim.x * 4 + threadIdx.x * 4; idx < total;
        idx += (long)(tb.first_block[e + 1] - tb.first_block[e]) * blockDim.x * 4) {
 #pragma unroll
@@ -403,7 +409,14 @@ __global__ void mse_kernel(const float* __restrict__ v, const float* __restrict_
 __global__ void sq_norm_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
   float s = 0.f;
   const long n4 = n / 4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+    const f32x4 a = load4(g + 4 * i), b = load4(g + 4 * (i + stride)), c = load4(g + 4 * (i + 2 * stride)), d = load4(g + 4 * (i + 3 * stride));
+    s += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    s += c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3] + d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = load4(g + 4 * i);
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
