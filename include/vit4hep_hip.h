@@ -121,6 +121,31 @@ size_t v4h_energy_plan_workspace_bytes(const v4h_energy_plan* plan, int32_t B);
 int32_t v4h_energy_forward(const v4h_energy_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
                            float* d_out, void* d_workspace, size_t workspace_bytes, int32_t flags, void* stream);
 
+/* ---- pre-/post-processing chain of the shape models, fused (experiments/calochallenge/transforms.py) ---------------------------
+ * forward = NormalizeByElayer (331-397) -> ScaleTotalEnergy (184-202) -> CutValues (291-311, identity forward) ->
+ * ExclusiveLogitTransform rescale=True (227-254, logit 11-18) -> GlobalStandardizeFromFile (21-64, stored statistics) -> LogEnergy
+ * (149-164) -> ScaleEnergy (205-224) -> AddFeaturesToCond (130-146) -> Reshape (314-328), i.e. the `transforms` mapping of
+ * configs/calochallenge/cfm/calochallenge_ds2.yaml:15-28; reverse = the same list backwards with rev=True (experiment.py:190-223). */
+typedef struct v4h_chain_spec {
+  int32_t n_layers;  /* NormalizeByElayer.n_layers (45)                                  */
+  int64_t n_voxels;  /* layer_boundaries[-1] (6480 ds2, 40500 ds3, 368 ds1 photons)     */
+  float eps;         /* NormalizeByElayer eps 1e-10                                      */
+  float norm_cut;    /* NormalizeByElayer cut 0.0                                        */
+  float factor;      /* ScaleTotalEnergy factor 0.35                                     */
+  float cut;         /* CutValues cut 1e-7                                               */
+  float delta;       /* ExclusiveLogitTransform delta 1e-6                               */
+  float mean, std;   /* GlobalStandardizeFromFile statistics (means.npy / stds.npy)      */
+  float alpha;       /* LogEnergy alpha 0                                                */
+  float e_min, e_max;/* ScaleEnergy 6.907755 / 13.815510                                 */
+} v4h_chain_spec;
+/* d_layer_bounds: int32 [n_layers + 1] first voxel of every layer + n_voxels.
+ * forward:  d_showers (B, n_voxels), d_energy (B) -> d_x (B, n_voxels) [= the Reshape'd network input], d_cond (B, n_layers + 1) = [u_0..u_{n-1} | energy]
+ * reverse:  d_samples (B, n_voxels), d_cond (B, n_layers + 1) -> d_showers (B, n_voxels), d_energy (B) */
+int32_t v4h_shape_preprocess(const v4h_chain_spec* spec, const int32_t* d_layer_bounds, const float* d_showers, const float* d_energy, float* d_x,
+                             float* d_cond, int32_t B, void* stream);
+int32_t v4h_shape_postprocess(const v4h_chain_spec* spec, const int32_t* d_layer_bounds, const float* d_samples, const float* d_cond, float* d_showers,
+                              float* d_energy, int32_t B, void* stream);
+
 /* ---- CFM step pieces ------------------------------------------------------------------------------------- */
 /* linear_trajectory + target (models/trajectories.py:5-8, models/base_model.py:214): x_t = (1-t) x0 + t x1, target = x1 - x0 */
 int32_t v4h_cfm_prepare(const float* d_x1, const float* d_x0, const float* d_t, float* d_xt, float* d_target, int32_t B, int64_t per_sample, void* stream);

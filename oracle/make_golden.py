@@ -34,6 +34,7 @@ sys.path.insert(0, REPO)
 REF = "/root/reference"
 
 from oracle import energy_oracle as E  # noqa: E402
+from oracle import transforms_oracle as TO  # noqa: E402
 from oracle import vit_cfm_oracle as O  # noqa: E402
 
 
@@ -332,6 +333,57 @@ def make_energy_case(name, cfg: E.EnergyConfig, B, seed, sample_specs):
     print(f"{name}: loss={loss.item():.6f} |v|={float(np.abs(out['velocity']).max()):.4f} nparams={int(out['nparams'])} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_transforms_case(name, layers, shape, B, seed, spec_kw):
+    """Pre-/post-processing chain of the shape models (configs/calochallenge/cfm/calochallenge_ds2.yaml:15-28) through the reference's
+    own transform classes.  `layers` = [(n_alpha, n_r), ...]: a synthetic binning file of the CaloChallenge XML format is written to a
+    temporary directory (the real ones are dataset assets, not part of the reference repository)."""
+    import tempfile
+
+    import experiments.calochallenge.transforms as T
+
+    tmp = tempfile.mkdtemp()
+    xml = os.path.join(tmp, "binning.xml")
+    rows = [f'<Layer id="{i}" r_edges="{",".join(str(float(k)) for k in range(nr + 1))}" n_bin_alpha="{na}"/>' for i, (na, nr) in enumerate(layers)]
+    with open(xml, "w") as fh:
+        fh.write('<Bins>\n<Bin pid="11" etaMin="0" etaMax="130" name="electron">\n' + "\n".join(rows) + "\n</Bin>\n</Bins>\n")
+    bounds = tuple(int(v) for v in np.cumsum([0] + [a * r for a, r in layers]))
+    spec = TO.ChainSpec(layer_boundaries=bounds, shape=tuple(shape), **spec_kw)
+    np.save(os.path.join(tmp, "means.npy"), np.float32(spec.mean))
+    np.save(os.path.join(tmp, "stds.npy"), np.float32(spec.std))
+    n_layers, V = spec.n_layers, spec.n_voxels
+    chain = [T.NormalizeByElayer(ptype=xml, xml_file="electron", cut=spec.norm_cut, eps=spec.eps),  # (sic) ptype carries the path: transforms.py:337-339
+             T.ScaleTotalEnergy(factor=spec.factor, n_layers=n_layers), T.CutValues(cut=spec.cut, n_layers=n_layers),
+             T.ExclusiveLogitTransform(delta=spec.delta, rescale=True), T.GlobalStandardizeFromFile(model_dir=tmp, eps=1.0e-6),
+             T.LogEnergy(alpha=spec.alpha), T.ScaleEnergy(e_min=spec.e_min, e_max=spec.e_max), T.AddFeaturesToCond(split_index=V), T.Reshape(shape=list(shape))]
+    assert tuple(int(v) for v in chain[0].layer_boundaries) == bounds
+    g = torch.Generator().manual_seed(seed)
+    # synthetic showers: sparse, positive, a few orders of magnitude; incident energies log-uniform in [1e3, 1e6] MeV
+    dep = torch.exp(torch.randn((B, V), generator=g) * 2.0) * (torch.rand((B, V), generator=g) < 0.3)
+    dep[0, bounds[1] : bounds[2]] = 0.0  # one empty layer
+    energy = torch.exp(torch.rand((B, 1), generator=g) * (spec.e_max - spec.e_min) + spec.e_min)
+    dep = dep / dep.sum(1, keepdim=True) * energy * (0.5 + 0.4 * torch.rand((B, 1), generator=g))
+    out = {"showers": dep.numpy().copy(), "energy": energy.numpy().copy(), "bounds": np.array(bounds)}
+    x, c = dep.clone(), energy.clone()
+    for fn in chain:
+        x, c = fn(x, c)
+    out["x"], out["c"] = x.numpy().copy(), c.numpy().copy()
+    xr, cr = x.clone(), c.clone()
+    for fn in chain[::-1]:
+        xr, cr = fn(xr, cr, rev=True)
+    out["roundtrip_showers"], out["roundtrip_energy"] = xr.numpy().copy(), cr.numpy().copy()
+    # model-like samples: standard-normal voxels and u's, condition energy in [0, 1]
+    smp = torch.randn((B, *shape), generator=g) * 1.5
+    cond = torch.cat([torch.randn((B, n_layers), generator=g) * 1.5, torch.rand((B, 1), generator=g)], dim=1)
+    out["samples"], out["cond"] = smp.numpy().copy(), cond.numpy().copy()
+    xs, cs = smp.clone(), cond.clone()
+    for fn in chain[::-1]:
+        xs, cs = fn(xs, cs, rev=True)
+    out["post_showers"], out["post_energy"] = xs.numpy().copy(), cs.numpy().copy()
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: V={V} layers={n_layers} |x|max={float(np.abs(out['x']).max()):.3f} sum(post)={float(out['post_showers'].sum()):.4e} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     _install_standins()
     sys.path.insert(0, REF)
@@ -348,6 +400,9 @@ def main():
     make_case("lemurs_d2_b2", O.lemurs(2), 2, 25, [("rk4_coarse", "rk4", 0.25)], 0, kind="lemurs")
     # the energy-model CFM
     make_energy_case("energy_ds2_b5", E.EnergyConfig(), 5, 31, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)])
+    # pre-/post-processing chain
+    make_transforms_case("transforms_ds2_b4", [(16, 9)] * 45, (1, 45, 16, 9), 4, 41, dict(mean=-1.7, std=2.9))
+    make_transforms_case("transforms_ds1ph_b6", [(1, 8), (10, 16), (10, 19), (1, 5), (1, 5)], (368,), 6, 42, dict(mean=-0.8, std=3.3, factor=0.5, cut=1.0e-6))
     make_energy_case("energy_small_b3", E.EnergyConfig(dims_in=30, dim_embedding=32, nhead=2, num_encoder_layers=1, num_decoder_layers=2,
                                                        dim_feedforward=256, encode_t_dim=32), 3, 32, [("rk4_coarse", "rk4", 0.25)])
 

@@ -41,6 +41,11 @@ class V4HEnergyConfig(C.Structure):
                                          "encode_t_dim", "mode")]
 
 
+class V4HChainSpec(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("n_voxels", C.c_int64)] + [(k, C.c_float) for k in ("eps", "norm_cut", "factor", "cut", "delta", "mean", "std", "alpha",
+                                                                                           "e_min", "e_max")]
+
+
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
 
@@ -63,6 +68,8 @@ SIGNATURES = {
     "v4h_energy_plan_param_shape": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "v4h_energy_plan_workspace_bytes": (_sz, [_vp, _i32]),
     "v4h_energy_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "v4h_shape_preprocess": (_i32, [C.POINTER(V4HChainSpec), _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "v4h_shape_postprocess": (_i32, [C.POINTER(V4HChainSpec), _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "v4h_cfm_prepare": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
