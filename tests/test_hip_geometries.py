@@ -176,8 +176,12 @@ def test_mapped_geometry_errors_are_loud():
     tok = torch.zeros((2, 88, 5), device=U.DEV)
     rc = _lib.load().v4h_op_patchify(plan.handle, _lib.ptr(x), _lib.ptr(tok), 2, _lib.stream_ptr(), None)
     assert rc != 0 and b"d_patch_map" in _lib.load().v4h_last_error()
+    good = core._patch_map.copy()
+    core.set_patch_map(np.zeros((3, 5), np.int32), 440)  # shape is checked against the live network when the plan is (re)built
     with pytest.raises(ValueError, match="patch map"):
-        core.set_patch_map(np.zeros((3, 5), np.int32), 440)
+        core._get_plan()
+    core.set_patch_map(good, 440)
+    assert core._get_plan().mapped
     with pytest.raises(ValueError, match=r"\[-1, 440\)"):
         core.set_patch_map(np.full((88, 5), 440, np.int32), 440)
 

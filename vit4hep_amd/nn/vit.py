@@ -95,6 +95,28 @@ class TimestepEmbedder(nn.Module):
 
 
 class ViT(nn.Module):
+    # patch_dim / condition_dim follow the LIVE embedders: fine-tuning re-shapes them after construction (weights interpolated to
+    # another input width via `.weight.data = ...`, modules replaced; reference experiment_finetuning.py:75-171), and nn.Linear's own
+    # `in_features` attribute is not updated by that - the weight's shape is the truth.
+    @property
+    def patch_dim(self):
+        xe = self._modules.get("x_embedder")
+        return int(xe.weight.shape[1]) if isinstance(xe, nn.Linear) else self.__dict__.get("_patch_dim0")
+
+    @patch_dim.setter
+    def patch_dim(self, v):
+        self.__dict__["_patch_dim0"] = int(v)
+
+    @property
+    def condition_dim(self):
+        ce = self._modules.get("c_embedder")
+        first = ce[0] if isinstance(ce, nn.Sequential) and len(ce) > 0 else None
+        return int(first.weight.shape[1]) if isinstance(first, nn.Linear) else self.__dict__.get("_condition_dim0")
+
+    @condition_dim.setter
+    def condition_dim(self, v):
+        self.__dict__["_condition_dim0"] = int(v)
+
     def __init__(self, param):
         super().__init__()
         for k, default in _DEFAULTS.items():
@@ -182,9 +204,8 @@ class ViT(nn.Module):
     def set_geometry(self, shape, patch_shape):
         """Regular grid: closed-form patch indexing inside the kernels."""
         shape, patch_shape = [int(s) for s in shape], [int(s) for s in patch_shape]
-        n = [s // p for s, p in zip(shape, patch_shape)]
-        if math.prod(n) != self.num_tokens or math.prod(patch_shape) * int(self.out_channels) != int(self.patch_dim):
-            raise ValueError(f"geometry shape={shape} patch_shape={patch_shape} does not match num_tokens={self.num_tokens} patch_dim={self.patch_dim}")
+        # not validated against the network here: a fine-tuning run builds the wrapper of the NEW dataset around the backbone's network and
+        # re-shapes embedders / position buffers afterwards (experiment_finetuning.py:25-34,75-171); _get_plan() checks at the first forward
         geom = ("grid", shape, patch_shape)
         if self._geometry != geom:
             self._patch_map, self._map_holes = None, False
@@ -196,8 +217,8 @@ class ViT(nn.Module):
         import numpy as np
 
         pm = np.ascontiguousarray(np.asarray(patch_map, dtype=np.int32))
-        if pm.shape != (self.num_tokens, int(self.patch_dim)):
-            raise ValueError(f"patch map shape {pm.shape} does not match (num_tokens={self.num_tokens}, patch_dim={int(self.patch_dim)})")
+        if pm.ndim != 2:
+            raise ValueError(f"patch map must be (tokens, patch_dim), got shape {pm.shape}")
         if pm.size and (int(pm.max()) >= int(voxels) or int(pm.min()) < -1):
             raise ValueError(f"patch map entries must lie in [-1, {int(voxels)})")
         if self._geometry is not None and self._geometry[0] == "map" and self._geometry[2] == int(voxels) and np.array_equal(self._patch_map, pm):
@@ -239,9 +260,32 @@ class ViT(nn.Module):
             self._dev_tables = (key, pm, pos)
         return self._dev_tables[1], self._dev_tables[2]
 
+    def _check_embedders(self):
+        if not isinstance(self._modules.get("x_embedder"), nn.Linear):
+            raise NotImplementedError("vit4hep_amd: x_embedder replaced by a non-Linear module (fine-tuning `map_x_embedding`: Sequential(Linear, SiLU, "
+                                      "x_embedder)) is not implemented in the HIP path; `interpolate` / `reinitialize_*` surgery is")
+        ce = self._modules.get("c_embedder")
+        if not (isinstance(ce, nn.Sequential) and len(ce) == 3 and isinstance(ce[0], nn.Linear) and isinstance(ce[2], nn.Linear)):
+            raise NotImplementedError("vit4hep_amd: c_embedder must be Sequential(Linear, SiLU, Linear) (fine-tuning `map_c_embedding` is not implemented)")
+        if not isinstance(getattr(self.final_layer, "linear", None), nn.Linear):
+            raise NotImplementedError("vit4hep_amd: final_layer must be a FinalLayer")
+
     def _get_plan(self):
+        self._check_embedders()
+        g = self.geometry()
+        T, P = self.num_tokens, int(self.patch_dim)
+        key = (T, P, int(self.condition_dim), int(self.final_layer.linear.weight.shape[0]), g[0], tuple(g[1]) if g[0] == "grid" else g[2], id(self._patch_map))
+        if self._plan is not None and getattr(self, "_plan_key", None) != key:  # embedders / head / position buffers were re-shaped
+            self._plan, self._infer_ws, self._dev_tables, self._infer_sig = None, {}, None, None
         if self._plan is None:
-            g = self.geometry()
+            if int(self.final_layer.linear.weight.shape[0]) != P * int(self.out_channels):
+                raise ValueError(f"final_layer emits {int(self.final_layer.linear.weight.shape[0])} features per token, x_embedder takes {P}")
+            if g[0] == "grid":
+                if math.prod(s // p for s, p in zip(g[1], g[2])) != T or math.prod(g[2]) * int(self.out_channels) != P:
+                    raise ValueError(f"geometry shape={g[1]} patch_shape={g[2]} does not match num_tokens={T} patch_dim={P}")
+            elif self._patch_map.shape != (T, P):
+                raise ValueError(f"patch map shape {self._patch_map.shape} does not match (num_tokens={T}, patch_dim={P})")
+            self._plan_key = key
             shape, patch_shape, mapped = (g[1], g[2], None) if g[0] == "grid" else (None, None, (self.num_tokens, int(self.patch_dim), g[2]))
             self._plan = _lib.Plan(shape, patch_shape, self.condition_dim, self.hidden_dim, self.depth, self.num_heads,
                                    int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped)
@@ -252,6 +296,7 @@ class ViT(nn.Module):
 
     def parameter_list(self):
         """Learnable tensors in the state_dict() order the C ABI expects (include/vit4hep_hip.h)."""
+        self._check_embedders()
         ps = [self.pos_embed_freqs, self.x_embedder.weight, self.x_embedder.bias,
               self.c_embedder[0].weight, self.c_embedder[0].bias, self.c_embedder[2].weight, self.c_embedder[2].bias,
               self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias, self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
