@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 2
+#define V4H_ABI_VERSION 3
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -38,6 +38,10 @@ typedef struct v4h_config {
   int32_t mlp_hidden;     /* int(hidden_dim * mlp_ratio) = 1920   nn/vit.py:312             */
   int32_t freq_dim;       /* 256 TimestepEmbedder                 nn/vit.py:359             */
   int32_t mode;           /* V4H_MODE_*                                                     */
+  int32_t x_embed_in;     /* 0, or: the x_embedder is Sequential(Linear(patch_dim -> x_embed_in), SiLU, Linear(x_embed_in -> hidden_dim)),
+                             the embedding mapper of fine-tuning (experiments/calochallenge/calochallenge_cfm/experiment_finetuning.py:80-91).
+                             Its two tensors (weight (x_embed_in, patch_dim), bias) come LAST in the parameter tables; x_embedder.{weight,bias} at
+                             indices 1, 2 are then those of the inner Linear, (hidden_dim, x_embed_in). */
 } v4h_config;
 
 typedef struct v4h_plan v4h_plan; /* host-side object: derived sizes and workspace offsets, no device state */

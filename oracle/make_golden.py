@@ -333,6 +333,51 @@ def make_energy_case(name, cfg: E.EnergyConfig, B, seed, sample_specs):
     print(f"{name}: loss={loss.item():.6f} |v|={float(np.abs(out['velocity']).max()):.4f} nparams={int(out['nparams'])} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_mapper_case(name, back: O.ViTConfig, new: O.ViTConfig, B, seed):
+    """Fine-tuning with an embedding mapper (experiments/calochallenge/calochallenge_cfm/experiment_finetuning.py:75-171, flags of
+    configs/calochallenge/finetuning/calochallenge_ds2tods3_ft.yaml: map_x_embedding, reinitialize_pos_embedding, reinitialize_final_layer):
+    the reference's own modules, surgery statements as in add_embedding_layers()."""
+    from nn.vit import FinalLayer
+
+    torch.manual_seed(99)
+    model = build_reference(back)                       # backbone network ...
+    model.shape, model.patch_shape = list(new.shape), list(new.patch_shape)  # ... inside the new dataset's wrapper
+    model.num_patches = list(new.num_patches)
+    load_fill(model, back)
+    net = model.net
+    mapper = nn.Linear(new.P, back.P)
+    net.x_embedder = nn.Sequential(mapper, nn.SiLU(), net.x_embedder)
+    net.num_patches = [list(new.num_patches)]
+    pos_z, pos_y, pos_x = net.create_meshgrid()
+    net.pos_z, net.pos_y, net.pos_x = pos_z, pos_y, pos_x
+    net.final_layer = FinalLayer(back.hidden_dim, new.P, 1)
+    with torch.no_grad():
+        for k, p_ in model.named_parameters():
+            if k.startswith("net.x_embedder.0.") or k.startswith("net.final_layer."):
+                p_.copy_(O.fill_tensor("ft/" + k[4:], tuple(p_.shape)))
+    model.train()
+    x, c, g = O.synthetic_batch(new, B, seed)
+    t, x0 = O.synthetic_noise(new, B, g)
+    x_t = (1 - t) * x0 + t * x
+    v = model.forward(x_t, t.view(-1, 1), c)
+    loss = ((v - (x - x0)) ** 2).mean()
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    out = {"x": x.numpy(), "c": c.numpy(), "t": t.numpy(), "x0": x0.numpy(), "velocity": v.detach().numpy(), "loss": np.float64(loss.item())}
+    names, norms = [], []
+    for k, p_ in model.named_parameters():
+        k = k[4:]
+        idx, vals = grad_probe(p_.grad)
+        out["gidx/" + k], out["gval/" + k] = idx, vals
+        names.append(k)
+        norms.append(float(p_.grad.double().norm()))
+    out["grad_norms"] = np.array(norms)
+    out["names"] = np.array(names)
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={loss.item():.6f} |g|={float(np.sqrt((np.array(norms) ** 2).sum())):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def make_transforms_case(name, layers, shape, B, seed, spec_kw):
     """Pre-/post-processing chain of the shape models (configs/calochallenge/cfm/calochallenge_ds2.yaml:15-28) through the reference's
     own transform classes.  `layers` = [(n_alpha, n_r), ...]: a synthetic binning file of the CaloChallenge XML format is written to a
@@ -400,6 +445,8 @@ def main():
     make_case("lemurs_d2_b2", O.lemurs(2), 2, 25, [("rk4_coarse", "rk4", 0.25)], 0, kind="lemurs")
     # the energy-model CFM
     make_energy_case("energy_ds2_b5", E.EnergyConfig(), 5, 31, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)])
+    # fine-tuning with an embedding mapper
+    make_mapper_case("ft_mapper_d2_b2", O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2), 2, 51)
     # pre-/post-processing chain
     make_transforms_case("transforms_ds2_b4", [(16, 9)] * 45, (1, 45, 16, 9), 4, 41, dict(mean=-1.7, std=2.9))
     make_transforms_case("transforms_ds1ph_b6", [(1, 8), (10, 16), (10, 19), (1, 5), (1, 5)], (368,), 6, 42, dict(mean=-0.8, std=3.3, factor=0.5, cut=1.0e-6))

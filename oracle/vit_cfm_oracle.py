@@ -191,6 +191,13 @@ def golden_fill(cfg: ViTConfig, dtype=torch.float32, bias_scale=0.05) -> dict:
     return out
 
 
+def fill_tensor(name: str, shape, dtype=torch.float32, bias_scale=0.05):
+    """The golden_fill rule for one tensor of any name / shape (tensors that fine-tuning surgery adds or re-shapes)."""
+    u = hash_uniform(name, int(np.prod(shape)))
+    v = u * math.sqrt(6.0 / (shape[0] + shape[1])) if len(shape) == 2 else u * bias_scale
+    return torch.from_numpy(v.reshape(shape)).to(dtype)
+
+
 def reference_init(cfg: ViTConfig, generator: torch.Generator, dtype=torch.float32) -> dict:
     """nn/vit.py:164-183: xavier-uniform Linear weights, zero biases, zero adaLN-last /
     final adaLN / final linear; pos_embed_freqs ~ N(0,1) (nn/vit.py:86)."""
@@ -356,7 +363,11 @@ def conditioning(p, t, c, cfg: ViTConfig):
 
 def vit_forward(p, xp, t, c, cfg: ViTConfig):
     """ViT.forward   nn/vit.py:185-206.  xp (B,T,P), t (B,1), c (B,K) -> (B,T,P)."""
-    x = linear(xp, p, "x_embedder") + pos_embedding(p["pos_embed_freqs"], cfg)
+    if "x_embedder.0.weight" in p:  # fine-tuning embedding mapper: Sequential(Linear, SiLU, x_embedder)   experiment_finetuning.py:80-91
+        x = linear(silu(linear(xp, p, "x_embedder.0")), p, "x_embedder.2")
+    else:
+        x = linear(xp, p, "x_embedder")
+    x = x + pos_embedding(p["pos_embed_freqs"], cfg)
     cs = silu(conditioning(p, t, c, cfg))
     for i in range(cfg.depth):
         x = dit_block(x, cs, p, i, cfg)

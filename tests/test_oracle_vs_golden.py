@@ -115,3 +115,20 @@ def test_hash_fill_is_platform_independent():
     v = O.hash_uniform("x_embedder.weight", 5)
     assert np.array_equal(u, v)
     assert not np.array_equal(u, O.hash_uniform("x_embedder.bias", 5))
+
+
+def test_embedding_mapper_oracle_vs_reference(golden):
+    """Fine-tuning mapper (x_embedder = Sequential(Linear, SiLU, x_embedder)): the oracle's optional mapper branch against vectors from
+    the reference's modules after the surgery of experiment_finetuning.py:75-171."""
+    g = golden("ft_mapper_d2_b2")
+    back, new = O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2)
+    p = dict(O.golden_fill(back))
+    p["x_embedder.2.weight"], p["x_embedder.2.bias"] = p.pop("x_embedder.weight"), p.pop("x_embedder.bias")
+    for k, shp in (("x_embedder.0.weight", (48, 24)), ("x_embedder.0.bias", (48,)), ("final_layer.linear.weight", (24, 480)), ("final_layer.linear.bias", (24,)),
+                   ("final_layer.adaLN_modulation.1.weight", (960, 480)), ("final_layer.adaLN_modulation.1.bias", (960,))):
+        p[k] = O.fill_tensor("ft/" + k, shp)
+    loss, v, grads = O.loss_and_grads(p, *(torch.from_numpy(g[k]) for k in ("x", "c", "t", "x0")), new)
+    assert rel(v.numpy(), g["velocity"]) < RTOL and abs(float(loss) - float(g["loss"])) / float(g["loss"]) < RTOL
+    names = [str(n) for n in g["names"]]
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    assert np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max() < 5e-5

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -33,6 +33,7 @@ class V4HConfig(C.Structure):
         ("mlp_hidden", C.c_int32),
         ("freq_dim", C.c_int32),
         ("mode", C.c_int32),
+        ("x_embed_in", C.c_int32),
     ]
 
 
@@ -172,7 +173,8 @@ class Plan:
     Regular grid: ``shape`` / ``patch_shape``.  General geometry: ``mapped=(tokens, patch_dim, voxels)`` (shape / patch_shape
     ignored); forward / backward calls then need the index map and position table (include/vit4hep_hip.h)."""
 
-    def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1, mapped=None):
+    def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1, mapped=None,
+                 x_embed_in=0):
         lib = load()
         cfg = V4HConfig()
         cfg.shape[:] = [int(v) for v in (shape if mapped is None else (0, 0, 0))]
@@ -185,6 +187,7 @@ class Plan:
         cfg.mlp_hidden = int(mlp_hidden)
         cfg.freq_dim = int(freq_dim)
         cfg.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        cfg.x_embed_in = int(x_embed_in)
         self.mode = cfg.mode
         self.cfg = cfg
         h = C.c_void_p()

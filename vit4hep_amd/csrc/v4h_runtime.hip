@@ -33,6 +33,10 @@ struct v4h_plan {
   v4h_config cfg;
   Mode mode;
   int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;
+  int Px, Pxpad;  // input width of the x_embedder Linear: P, or x_embed_in behind an embedding mapper
+  bool mapper() const { return cfg.x_embed_in > 0; }
+  int xmw() const { return nparams() - 2; }  // mapper weight / bias: the last two tensors
+  int xmb() const { return nparams() - 1; }
   PatchGeom pg;
   bool mapped = false;  // general geometry: gather / scatter through a caller-provided index map, positions from a caller-provided table
   long V = 0;           // voxels per sample
@@ -141,6 +145,9 @@ static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int pa
     p->V = voxels;
   }
   p->Ppad = round_up(p->P, 32);
+  V4H_CHECK_ARG(c->x_embed_in >= 0, "plan_create: x_embed_in %d", c->x_embed_in);
+  p->Px = c->x_embed_in > 0 ? c->x_embed_in : p->P;
+  p->Pxpad = round_up(p->Px, 32);
   p->D = c->hidden_dim;
   p->H = c->num_heads;
   p->DH = p->D / p->H;
@@ -152,7 +159,7 @@ static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int pa
   auto add = [&](int r, int cc) { p->rows.push_back(r); p->cols.push_back(cc); };
   const int D = p->D;
   add(D / 6, 0);
-  add(D, p->P); add(D, 0);
+  add(D, p->Px); add(D, 0);
   add(D, p->Kc); add(D, 0); add(D, D); add(D, 0);
   add(D, p->F); add(D, 0); add(D, D); add(D, 0);
   for (int i = 0; i < p->depth; ++i) {
@@ -161,6 +168,7 @@ static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int pa
     add(6 * D, D); add(6 * D, 0);
   }
   add(p->P, D); add(p->P, 0); add(2 * D, D); add(2 * D, 0);
+  if (p->mapper()) { add(p->Px, p->P); add(p->Px, 0); }
   *out = p;
   return V4H_OK;
 }
@@ -200,6 +208,8 @@ struct WS {
   std::vector<char*> wop;       // operand-typed (cast / padded) weights, null where the f32 parameter itself is used
   float* linb_pad;
   char *xp, *temb, *ht, *cpad, *hc, *silu_c, *uf;
+  char *xpm, *xmb_pad, *dxpre;   // embedding mapper (fine-tuning): gathered input patches, padded bias, gradient of the pre-activation
+  float *xpre, *gxmw, *gxmb;
   float *pe, *ht_pre, *hc_pre, *cond, *modf, *meanf, *rstdf;
   std::vector<float*> mod, X;
   std::vector<BlockWS> blk;
@@ -235,13 +245,20 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     if (p.cols[i] == 0) continue;
     int rp = p.rows[i], cp = p.cols[i];
     bool padded = false;
-    if (i == P_XW) { cp = p.Ppad; padded = true; }
+    if (i == P_XW) { cp = p.Pxpad; padded = true; }
+    if (p.mapper() && i == p.xmw()) { rp = p.Pxpad; cp = p.Ppad; padded = true; }
     if (i == P_C0W) { cp = p.Kcpad; padded = true; }
     if (i == p.fin(F_LINW)) { rp = p.Ppad; padded = true; }
     if (p.mode == MODE_BF16 || padded) w.wop[i] = take((size_t)rp * cp * es);
   }
   w.linb_pad = (float*)take(p.Ppad * 4);
-  w.xp = take(BT * p.Ppad * es);
+  w.xp = take(BT * p.Pxpad * es);
+  w.xpm = w.xmb_pad = nullptr; w.xpre = nullptr;
+  if (p.mapper()) {
+    w.xpm = take(BT * p.Ppad * es);                    // gathered patches of the new geometry (mapper input)
+    w.xpre = (float*)take(BT * p.Pxpad * 4);           // mapper pre-activation (for silu')
+    w.xmb_pad = take((size_t)p.Pxpad * 4);             // mapper bias, zero-padded
+  }
   w.pe = (float*)take((size_t)p.T * D * 4);
   w.temb = take((size_t)B * p.F * es);
   w.ht_pre = (float*)take((size_t)B * D * 4);
@@ -282,7 +299,12 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     for (int i = 0; i < p.depth; ++i) w.dmod[i] = (float*)take((size_t)B * 6 * D * 4);
     w.dmodf = (float*)take((size_t)B * 2 * D * 4);
     w.dsilu = (float*)take((size_t)B * D * 4);
-    w.gxw = (float*)take((size_t)D * p.Ppad * 4);
+    w.gxw = (float*)take((size_t)D * p.Pxpad * 4);
+    w.dxpre = nullptr; w.gxmw = nullptr; w.gxmb = nullptr;
+    if (p.mapper()) {
+      w.gxmw = (float*)take((size_t)p.Pxpad * p.Ppad * 4);
+      w.gxmb = (float*)take((size_t)p.Pxpad * 4);
+    }
     w.gc0w = (float*)take((size_t)D * p.Kcpad * 4);
     w.glin = (float*)take((size_t)p.Ppad * D * 4);
     w.glinb = (float*)take((size_t)p.Ppad * 4);
@@ -293,6 +315,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     w.G = (float*)take((size_t)p.T * D * 4);
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
+    if (p.mapper()) w.dxpre = take(BT * p.Pxpad * es);
     w.dy = take(BT * D * es);
     w.dy2 = take(BT * D * es);
     w.dhpre = take(BT * M * es);
@@ -399,23 +422,31 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     for (int i = 0; i < p->nparams() && !reuse; ++i) {
       if (!w.wop[i]) continue;
       int rp = p->rows[i], cp = p->cols[i];
-      if (i == P_XW) cp = p->Ppad;
+      if (i == P_XW) cp = p->Pxpad;
+      if (p->mapper() && i == p->xmw()) { rp = p->Pxpad; cp = p->Ppad; }
       if (i == P_C0W) cp = p->Kcpad;
       if (i == p->fin(F_LINW)) rp = p->Ppad;
       items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
     }
     if (!reuse) items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
+    if (!reuse && p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
     items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
-  if (pmap) RUN(patchify_map(m, false, x, pmap, w.xp, B, p->V, T, p->P, p->Ppad, c.s));
-  else RUN(patchify(m, x, w.xp, B, p->pg, p->P, p->Ppad, c.s));
+  char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
+  if (pmap) RUN(patchify_map(m, false, x, pmap, patches, B, p->V, T, p->P, p->Ppad, c.s));
+  else RUN(patchify(m, x, patches, B, p->pg, p->P, p->Ppad, c.s));
+  if (p->mapper()) {  // fine-tuning embedding mapper: xp = silu(patches Wm^T + bm)   (experiment_finetuning.py:80-91)
+    GemmArgs a = gargs(w.xpm, p->Ppad, c.W(p->xmw()), p->Ppad, BT, p->Pxpad, p->Ppad);
+    a.e.out = w.xp; a.e.ldo = p->Pxpad; a.e.out2 = training ? w.xpre : nullptr; a.e.ldo2 = p->Pxpad; a.e.bias = (const float*)w.xmb_pad;
+    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+  }
   if (reuse) {}
   else if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, w.pe, T, D, c.s));
   else RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
   {
-    GemmArgs a = gargs(w.xp, p->Ppad, c.W(P_XW), p->Ppad, BT, D, p->Ppad);
+    GemmArgs a = gargs(w.xp, p->Pxpad, c.W(P_XW), p->Pxpad, BT, D, p->Pxpad);
     a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T;
     RUN(gemm_fwd(m, EPI_EMBED, a, c.s));
   }
@@ -587,8 +618,16 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       RUN(adaln_backward(c, w.dmod[i], 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
     } else {
       // --- embedders (nn/vit.py:76-82,193-199) ---
-      RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Ppad, p->Ppad, BT, w.gxw, p->Ppad, (float*)grads[P_XB]));
-      RUN(unpad_f32(w.gxw, p->Ppad, (float*)grads[P_XW], D, p->P, c.s));
+      RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Pxpad, p->Pxpad, BT, w.gxw, p->Pxpad, (float*)grads[P_XB]));
+      RUN(unpad_f32(w.gxw, p->Pxpad, (float*)grads[P_XW], D, p->Px, c.s));
+      if (p->mapper()) {  // d pre = (d x0 . Wx) * silu'(pre) ; d Wm = d pre^T patches ; d bm = column sums
+        GemmArgs a = gargs(w.dx0_t, D, c.W(P_XW), p->Pxpad, BT, p->Pxpad, D);
+        a.e.out = w.dxpre; a.e.ldo = p->Pxpad; a.e.auxf = w.xpre; a.e.ld_auxf = p->Pxpad;
+        RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
+        RUN(wgrad(c, w.dxpre, p->Pxpad, p->Pxpad, w.xpm, p->Ppad, p->Ppad, BT, w.gxmw, p->Ppad, w.gxmb));
+        RUN(unpad_f32(w.gxmw, p->Ppad, (float*)grads[p->xmw()], p->Px, p->P, c.s));
+        RUN(unpad_f32(w.gxmb, 1, (float*)grads[p->xmb()], p->Px, 1, c.s));
+      }
       if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
       else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));

@@ -101,7 +101,20 @@ class ViT(nn.Module):
     @property
     def patch_dim(self):
         xe = self._modules.get("x_embedder")
-        return int(xe.weight.shape[1]) if isinstance(xe, nn.Linear) else self.__dict__.get("_patch_dim0")
+        if isinstance(xe, nn.Linear):
+            return int(xe.weight.shape[1])
+        if self._is_mapper(xe):  # Sequential(mapper Linear, SiLU, x_embedder): the network sees the mapper's input width
+            return int(xe[0].weight.shape[1])
+        return self.__dict__.get("_patch_dim0")
+
+    @staticmethod
+    def _is_mapper(xe):
+        return isinstance(xe, nn.Sequential) and len(xe) == 3 and isinstance(xe[0], nn.Linear) and isinstance(xe[1], nn.SiLU) and isinstance(xe[2], nn.Linear)
+
+    def x_embed_in(self):
+        """Input width of the inner x_embedder Linear behind a fine-tuning embedding mapper, else 0."""
+        xe = self._modules.get("x_embedder")
+        return int(xe[2].weight.shape[1]) if self._is_mapper(xe) else 0
 
     @patch_dim.setter
     def patch_dim(self, v):
@@ -261,9 +274,12 @@ class ViT(nn.Module):
         return self._dev_tables[1], self._dev_tables[2]
 
     def _check_embedders(self):
-        if not isinstance(self._modules.get("x_embedder"), nn.Linear):
-            raise NotImplementedError("vit4hep_amd: x_embedder replaced by a non-Linear module (fine-tuning `map_x_embedding`: Sequential(Linear, SiLU, "
-                                      "x_embedder)) is not implemented in the HIP path; `interpolate` / `reinitialize_*` surgery is")
+        xe = self._modules.get("x_embedder")
+        if not (isinstance(xe, nn.Linear) or self._is_mapper(xe)):
+            raise NotImplementedError("vit4hep_amd: x_embedder must be a Linear or the fine-tuning mapper Sequential(Linear, SiLU, Linear) "
+                                      "(experiment_finetuning.py:80-91)")
+        if self._is_mapper(xe) and int(xe[0].weight.shape[0]) != int(xe[2].weight.shape[1]):
+            raise ValueError("embedding mapper: output width of the mapper differs from the input width of the x_embedder")
         ce = self._modules.get("c_embedder")
         if not (isinstance(ce, nn.Sequential) and len(ce) == 3 and isinstance(ce[0], nn.Linear) and isinstance(ce[2], nn.Linear)):
             raise NotImplementedError("vit4hep_amd: c_embedder must be Sequential(Linear, SiLU, Linear) (fine-tuning `map_c_embedding` is not implemented)")
@@ -274,7 +290,8 @@ class ViT(nn.Module):
         self._check_embedders()
         g = self.geometry()
         T, P = self.num_tokens, int(self.patch_dim)
-        key = (T, P, int(self.condition_dim), int(self.final_layer.linear.weight.shape[0]), g[0], tuple(g[1]) if g[0] == "grid" else g[2], id(self._patch_map))
+        key = (T, P, int(self.condition_dim), int(self.final_layer.linear.weight.shape[0]), g[0], tuple(g[1]) if g[0] == "grid" else g[2], id(self._patch_map),
+               self.x_embed_in())
         if self._plan is not None and getattr(self, "_plan_key", None) != key:  # embedders / head / position buffers were re-shaped
             self._plan, self._infer_ws, self._dev_tables, self._infer_sig = None, {}, None, None
         if self._plan is None:
@@ -288,7 +305,8 @@ class ViT(nn.Module):
             self._plan_key = key
             shape, patch_shape, mapped = (g[1], g[2], None) if g[0] == "grid" else (None, None, (self.num_tokens, int(self.patch_dim), g[2]))
             self._plan = _lib.Plan(shape, patch_shape, self.condition_dim, self.hidden_dim, self.depth, self.num_heads,
-                                   int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped)
+                                   int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped,
+                                   x_embed_in=self.x_embed_in())
             got = [tuple(p.shape) for p in self.parameter_list()]
             if got != self._plan.shapes:
                 raise RuntimeError(f"parameter inventory differs from the library's: {got} vs {self._plan.shapes}")
@@ -297,7 +315,9 @@ class ViT(nn.Module):
     def parameter_list(self):
         """Learnable tensors in the state_dict() order the C ABI expects (include/vit4hep_hip.h)."""
         self._check_embedders()
-        ps = [self.pos_embed_freqs, self.x_embedder.weight, self.x_embedder.bias,
+        mapper = self._is_mapper(self.x_embedder)
+        xlin = self.x_embedder[2] if mapper else self.x_embedder
+        ps = [self.pos_embed_freqs, xlin.weight, xlin.bias,
               self.c_embedder[0].weight, self.c_embedder[0].bias, self.c_embedder[2].weight, self.c_embedder[2].bias,
               self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias, self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
         for b in self.blocks:
@@ -305,6 +325,8 @@ class ViT(nn.Module):
                    b.mlp.fc2.weight, b.mlp.fc2.bias, b.adaLN_modulation[1].weight, b.adaLN_modulation[1].bias]
         ps += [self.final_layer.linear.weight, self.final_layer.linear.bias,
                self.final_layer.adaLN_modulation[1].weight, self.final_layer.adaLN_modulation[1].bias]
+        if mapper:  # the C ABI takes the mapper's two tensors last (include/vit4hep_hip.h: v4h_config.x_embed_in)
+            ps += [self.x_embedder[0].weight, self.x_embedder[0].bias]
         return ps
 
     def inference_workspace(self, B, device):
