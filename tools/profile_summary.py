@@ -14,7 +14,7 @@ def short(n):
         m = re.match(r"_Z15v4h_gemm_kernelI7GemmCfgI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)", n)
     if m:
         t, _, pks, qks, bi, bj, bk, epi, cs = m.groups()
-        epis = ["STORE","STORE_F32","SILU","COND_SUM","EMBED","GATE_RESID","GELU","DGELU","DSILU","ATOMIC_F32","ACCUM_F32","UNPATCH","SLAB_F32"]
+        epis = ["STORE","STORE_F32","SILU","COND_SUM","EMBED","GATE_RESID","GELU","DGELU","DSILU","ATOMIC_F32","ACCUM_F32","UNPATCH","SLAB_F32","RELU","ROWADD_SILU"]
         lay = {("0","0"):"fwd",("0","1"):"dgrad",("1","1"):"wgrad"}[(pks,qks)]
         return f"gemm<{'bf16' if t=='DF16b' else 'f32'},{lay},{bi}x{bj}x{bk},{epis[int(epi)]}{',colsum' if cs=='1' else ''}>"
     m = re.match(r"_ZN(?:3v4h)?12_GLOBAL__N_1(\d+)([a-z_0-9]+)I(DF16b|f)", n)

@@ -167,40 +167,62 @@ template <typename T> __global__ void cond_embed_kernel(const float* __restrict_
 // Up to two chained affine LayerNorms (eps 1e-5) over rows of d <= 512 (d % 64 == 0), each optionally preceded by adding a per-sample
 // vector (the cross-attention output of a one-token memory); in place on the f32 rows, plus a mode-typed copy for the next GEMM.
 struct LnStage { const float* add; int ld_add; const float* gamma; const float* beta; };
-template <typename T> __global__ __launch_bounds__(256) void ln_affine_kernel(float* __restrict__ x, T* __restrict__ xT, LnStage s0, LnStage s1, int nstage, int rows, int rows_per_sample, int d) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int b = row / rows_per_sample;
-  float v[8];
-  const int nv = d / 64;
+// A group of 16 lanes owns a row (4 rows per wave, 16 per workgroup): d <= 512 gives each lane d / 16 <= 32 values as float4s.  One wave
+// per row left 62 of 64 lanes idle at d = 128 and made the kernel a chain of shuffle latencies (10.7 us per call, measured).
+template <typename T, int NV4> __global__ __launch_bounds__(256) void ln_affine_kernel(float* __restrict__ x, T* __restrict__ xT, LnStage s0, LnStage s1, int nstage, int rows,
+                                                                                   int rows_per_sample, int d) {
+  const int gl = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;            // whole 16-lane groups go idle together; the shuffles below stay inside a group
+  const int r = live ? row : rows - 1;
+  const int b = r / rows_per_sample;
+  f32x4 v[NV4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = k < nv ? x[(long)row * d + lane + 64 * k] : 0.f;
+  for (int k = 0; k < NV4; ++k) {
+    const int c = 4 * gl + 64 * k;
+    v[k] = c < d ? load4(x + (long)r * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int st = 0; st < nstage; ++st) {
     const LnStage& s = st == 0 ? s0 : s1;
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < nv) {
-        if (s.add) v[k] += s.add[(long)b * s.ld_add + lane + 64 * k];
-        sum += v[k];
+    for (int k = 0; k < NV4; ++k) {
+      const int c = 4 * gl + 64 * k;
+      if (c < d) {
+        if (s.add) v[k] += load4(s.add + (long)b * s.ld_add + c);
+        sum += v[k][0] + v[k][1] + v[k][2] + v[k][3];
       }
-    const float mu = wave_sum(sum) / (float)d;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mu = sum / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < nv) q += (v[k] - mu) * (v[k] - mu);
-    const float rs = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < nv) v[k] = (v[k] - mu) * rs * s.gamma[lane + 64 * k] + s.beta[lane + 64 * k];
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (k < nv) {
-      x[(long)row * d + lane + 64 * k] = v[k];
-      xT[(long)row * d + lane + 64 * k] = (T)v[k];
+    for (int k = 0; k < NV4; ++k) {
+      const int c = 4 * gl + 64 * k;
+      if (c < d) {
+        const f32x4 dv = v[k] - mu;
+        q += dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3];
+      }
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rs = 1.0f / sqrtf(q / (float)d + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int c = 4 * gl + 64 * k;
+      if (c < d) v[k] = (v[k] - mu) * rs * load4(s.gamma + c) + load4(s.beta + c);
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) {
+    const int c = 4 * gl + 64 * k;
+    if (c < d) {
+      store4(x + (long)row * d + c, v[k]);
+      store4(xT + (long)row * d + c, v[k]);
+    }
+  }
 }
 // head, last Linear(ff -> 1): out[row] = z[row] . w + b   transformer_cfm.py:66-70
 template <typename T> __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ z, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out, int rows, int ff) {
@@ -260,9 +282,14 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
     RUN(cast_pad_many(m, items.data(), (int)items.size(), s));
   }
   auto ln = [&](float* xr, void* xT, LnStage s0, LnStage s1, int nstage, int rows, int rps) -> int {
-    const dim3 grid((rows + 3) / 4);
-    if (m == MODE_BF16) hipLaunchKernelGGL(ln_affine_kernel<bf16>, grid, dim3(256), 0, s, xr, (bf16*)xT, s0, s1, nstage, rows, rps, d);
-    else hipLaunchKernelGGL(ln_affine_kernel<float>, grid, dim3(256), 0, s, xr, (float*)xT, s0, s1, nstage, rows, rps, d);
+    const dim3 grid((rows + 15) / 16);
+    if (d <= 128) {
+      if (m == MODE_BF16) hipLaunchKernelGGL((ln_affine_kernel<bf16, 2>), grid, dim3(256), 0, s, xr, (bf16*)xT, s0, s1, nstage, rows, rps, d);
+      else hipLaunchKernelGGL((ln_affine_kernel<float, 2>), grid, dim3(256), 0, s, xr, (float*)xT, s0, s1, nstage, rows, rps, d);
+    } else {
+      if (m == MODE_BF16) hipLaunchKernelGGL((ln_affine_kernel<bf16, 8>), grid, dim3(256), 0, s, xr, (bf16*)xT, s0, s1, nstage, rows, rps, d);
+      else hipLaunchKernelGGL((ln_affine_kernel<float, 8>), grid, dim3(256), 0, s, xr, (float*)xT, s0, s1, nstage, rows, rps, d);
+    }
     V4H_CHECK_LAUNCH("ln_affine");
     return V4H_OK;
   };
