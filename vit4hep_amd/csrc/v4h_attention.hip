@@ -461,7 +461,10 @@ template <typename T, int NW, int DHT = 80> int attn_fwd_launch(const void* qkv,
   const size_t lds = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
   int rc = set_lds(attn_fwd_kernel<T, DHT, NW>, lds, "attn_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DHT, NW>), dim3(B * H, 1), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
+  // one round of NW query tiles per workgroup: a (batch, head) item with more tiles is spread over gridDim.y workgroups, each staging the
+  // K/V chunks once - the same number of chunk loads as one workgroup doing several rounds, but B*H = 192..384 items no longer leave CUs idle
+  const int ny = ((Tn + 15) / 16 + NW - 1) / NW;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DHT, NW>), dim3(B * H, ny), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, 1.0f / sqrtf((float)DH));
   V4H_CHECK_LAUNCH("attn_fwd");
   return V4H_OK;
 }
@@ -498,12 +501,13 @@ template <typename T, int NW> int attn_bwd_launch(const void* qkv, const void* o
   const size_t lds_q = 2 * (size_t)C::TILE_ELEMS * sizeof(T) + 64;
   int rc = set_lds(attn_bwd_dq_kernel<T, 80, NW>, lds_q, "attn_bwd_dq");
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_q, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  const int ny = ((Tn + 15) / 16 + NW - 1) / NW;  // as in the forward: one round of tiles per workgroup
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 80, NW>), dim3(B * H, ny), dim3(64 * NW), lds_q, s, (const T*)qkv, (const T*)o, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
   V4H_CHECK_LAUNCH("attn_bwd_dq");
   const size_t lds_kv = lds_q + 2 * KC * sizeof(float);
   rc = set_lds(attn_bwd_dkv_kernel<T, 80, NW>, lds_kv, "attn_bwd_dkv");
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 80, NW>), dim3(B * H, 1), dim3(64 * NW), lds_kv, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 80, NW>), dim3(B * H, ny), dim3(64 * NW), lds_kv, s, (const T*)qkv, (const T*)dout, lse, delta, (T*)dqkv, Tn, H, scale);
   V4H_CHECK_LAUNCH("attn_bwd_dkv");
   return V4H_OK;
 }
