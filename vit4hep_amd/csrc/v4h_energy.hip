@@ -13,6 +13,7 @@
 // Per evaluation that leaves, on (B * dims_in) token rows: 4 x [in_proj GEMM, attention (head_dim 32), out_proj GEMM + residual,
 // LayerNorm x2 fused (+ cross vector), FFN GEMM relu, FFN GEMM + residual, LayerNorm] + embedding + head.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -91,10 +92,16 @@ struct EWS {
   std::vector<char*> wop;  // mode-typed operand copies of the GEMM weights (bf16 mode only)
   float *ones, *temb, *hv, *h, *m, *cv, *lse;
   char *gfp, *tembT, *hT, *qkv, *o, *f, *z, *mT, *mv, *mo, *mf, *cvt;
+  char* fstream;  // packed weight images of the resident decoder (bf16 mode)
 };
 bool is_gemm_weight(const v4h_energy_plan& p, int i) {
   if (p.cols[i] == 0) return false;
   return !(i == v4h_energy_plan::XE_W || i == v4h_energy_plan::CE_W || i == v4h_energy_plan::POS_X || i == v4h_energy_plan::POS_C || i == p.out_w());
+}
+// the resident decoder (one launch per evaluation) serves the shipped configuration in throughput mode; V4H_ENERGY_FUSED=0 keeps the composed path
+bool use_fused(const v4h_energy_plan& p) {
+  static const bool enabled = !(getenv("V4H_ENERGY_FUSED") && getenv("V4H_ENERGY_FUSED")[0] == '0');
+  return enabled && p.mode == MODE_BF16 && energy_fused_supported(p.d, p.ff, p.H, p.L, p.nd, p.te);
 }
 size_t elayout(const v4h_energy_plan& p, int B, char* base, EWS& w) {
   size_t off = 0;
@@ -126,6 +133,7 @@ size_t elayout(const v4h_energy_plan& p, int B, char* base, EWS& w) {
   w.mf = take((size_t)B * ff * es);
   w.cvt = take((size_t)B * d * es);
   w.cv = (float*)take((size_t)p.nd * B * d * 4);
+  w.fstream = use_fused(p) ? take(energy_fused_stream_bytes(p.nd)) : nullptr;
   return off;
 }
 
@@ -340,6 +348,14 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
       RUN(gemm_to(EPI_STORE, w.mT, d, W(p->dec(i, PL::D_CA + PL::IN_W)) + (size_t)2 * d * d * es, d, pf(p->dec(i, PL::D_CA + PL::IN_B)) + 2 * d, w.cvt, d, B, d, d));
       RUN(gemm_to(EPI_STORE_F32, w.cvt, d, W(p->dec(i, PL::D_CA + PL::OUT_W)), d, pf(p->dec(i, PL::D_CA + PL::OUT_B)), w.cv + (size_t)i * B * d, d, B, d, d));
     }
+  }
+
+  // Resident decoder: embedding, all decoder layers and the head in one launch.  One workgroup per sample is bound by the latency of its
+  // weight stream (109 images, one barrier each: ~150 us per sample and CU), which wins while the batch leaves the composed path's
+  // contractions latency-bound too (batch 256: 0.175 vs 0.331 ms per evaluation) and loses once those fill the chip (batch 2048: 1.23 vs 1.08 ms).
+  if (w.fstream && B <= 1024) {
+    if (!reuse) RUN(energy_fused_pack(params, w.fstream, p->nd, te, p->dec(0, 0), PL::D_COUNT, p->dec_norm(0), PL::HEAD_W, PL::HEAD_B, p->out_w(), p->out_b(), s));
+    return energy_fused_decoder(w.fstream, x, w.temb, pf(PL::XE_W), pf(PL::XE_B), pf(PL::POS_X), w.cv, w.hv, out, B, L, p->nd, te, s);
   }
 
   // 3. target embedding   transformer_cfm.py:84-90

@@ -71,4 +71,12 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
 int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
 
+// ---- energy model, resident decoder (v4h_energy_fused.hip; bf16 mode) ----
+size_t energy_fused_stream_bytes(int nd);
+bool energy_fused_supported(int d, int ff, int H, int L, int nd, int te);
+int energy_fused_pack(const void* const* params, char* stream, int nd, int te, int dec0, int dcount, int dec_norm, int head_w, int head_b, int out_w, int out_b,
+                      hipStream_t s);
+int energy_fused_decoder(const char* stream, const float* x, const float* temb, const float* wx, const float* bx, const float* pos, const float* cv, const float* hv,
+                         float* out, int B, int L, int nd, int te, hipStream_t s);
+
 }  // namespace v4h
