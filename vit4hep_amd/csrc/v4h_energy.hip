@@ -164,8 +164,9 @@ template <typename T> __global__ void energy_embed_kernel(const float* __restric
 }
 // compute_embedding(condition, 1): c * w + b + pos_c[0]   transformer_cfm.py:91-94
 template <typename T> __global__ void cond_embed_kernel(const float* __restrict__ c, const float* __restrict__ wc, const float* __restrict__ bc, const float* __restrict__ posc,
-                                                        float* __restrict__ m, T* __restrict__ mT, int B, int d) {
+                                                        float* __restrict__ m, T* __restrict__ mT, float* __restrict__ ones, int B, int d) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < d) ones[idx] = 1.0f;  // the gate of ones for the residual epilogues below (the Fourier-feature kernel does not run on the resident-decoder path)
   if (idx >= B * d) return;
   const int j = idx % d;
   const float v = c[idx / d] * wc[j] + bc[j] + posc[j];
@@ -314,8 +315,13 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
     return gemm_fwd(m, epi, a, s);
   };
 
+  // Resident decoder: time embedding, target embedding, all decoder layers and the head in one launch.  One workgroup per sample is bound
+  // by the latency of its weight stream (109 images, one barrier each: ~130 us per sample and CU), which wins while the batch leaves the
+  // composed path's contractions latency-bound too and loses once those fill the chip (batch 2048: 1.23 vs 1.08 ms per evaluation).
+  const bool fused = w.fstream && B <= 1024;
+
   // 1. time embedding (per evaluation)   transformer_cfm.py:39-42
-  {
+  if (!fused) {
     const int n = B * te > d ? B * te : d;
     if (m == MODE_BF16) hipLaunchKernelGGL(gfp_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, s, t, pf(PL::GFP_W), (bf16*)w.gfp, w.ones, B, te, d);
     else hipLaunchKernelGGL(gfp_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, t, pf(PL::GFP_W), (float*)w.gfp, w.ones, B, te, d);
@@ -330,7 +336,7 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
   if (!same_c) {
     by_mode(m, [&](auto* tag) {
       using T = std::remove_pointer_t<decltype(tag)>;
-      hipLaunchKernelGGL(cond_embed_kernel<T>, dim3((B * d + 255) / 256), dim3(256), 0, s, cnd, pf(PL::CE_W), pf(PL::CE_B), pf(PL::POS_C), w.m, (T*)w.mT, B, d);
+      hipLaunchKernelGGL(cond_embed_kernel<T>, dim3((B * d + 255) / 256), dim3(256), 0, s, cnd, pf(PL::CE_W), pf(PL::CE_B), pf(PL::POS_C), w.m, (T*)w.mT, w.ones, B, d);
       return 0;
     });
     V4H_CHECK_LAUNCH("cond_embed");
@@ -350,12 +356,10 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
     }
   }
 
-  // Resident decoder: embedding, all decoder layers and the head in one launch.  One workgroup per sample is bound by the latency of its
-  // weight stream (109 images, one barrier each: ~150 us per sample and CU), which wins while the batch leaves the composed path's
-  // contractions latency-bound too (batch 256: 0.175 vs 0.331 ms per evaluation) and loses once those fill the chip (batch 2048: 1.23 vs 1.08 ms).
-  if (w.fstream && B <= 1024) {
+  if (fused) {
     if (!reuse) RUN(energy_fused_pack(params, w.fstream, p->nd, te, p->dec(0, 0), PL::D_COUNT, p->dec_norm(0), PL::HEAD_W, PL::HEAD_B, p->out_w(), p->out_b(), s));
-    return energy_fused_decoder(w.fstream, x, w.temb, pf(PL::XE_W), pf(PL::XE_B), pf(PL::POS_X), w.cv, w.hv, out, B, L, p->nd, te, s);
+    return energy_fused_decoder(w.fstream, x, t, pf(PL::GFP_W), pf(PL::TE_W), pf(PL::TE_B), pf(PL::XE_W), pf(PL::XE_B), pf(PL::POS_X), w.cv, pf(PL::HEAD_W),
+                                pf(PL::HEAD_B), out, B, L, p->nd, te, s);
   }
 
   // 3. target embedding   transformer_cfm.py:84-90

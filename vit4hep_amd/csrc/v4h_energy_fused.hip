@@ -96,10 +96,11 @@ __global__ __launch_bounds__(256) void energy_pack_kernel(PackArgs a) {
 struct FusedArgs {
   const char* stream;   // packed images
   const float* x;       // (B, L)
-  const float* temb;    // (B, te) f32 time embedding
+  const float* t;       // (B)
+  const float* gfp_w; const float* te_w; const float* te_b;  // time_embed: GaussianFourierProjection.W (te/2), Linear (te, te)
   const float* wx; const float* bx; const float* pos;  // x_embed.weight (e,1), bias, pos_embed_x (L, e)
   const float* cv;      // (nd, B, d) cross-attention vectors
-  const float* hv;      // (B, ff) head time term + bias
+  const float* head_w; const float* head_b;  // layer.weight (ff, te + d): its first te columns give the per-sample time term of the head
   float* out;           // (B, L)
   int B, L, nd, te;
 };
@@ -133,14 +134,42 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
   const int b = blockIdx.x, L = a.L;
   const int nimg = a.nd * IMGS_PER_LAYER + IMGS_HEAD;
 
-  // ---- per-sample vectors and the target embedding (transformer_cfm.py:84-90), before the DMA pipeline starts
+  // ---- per-sample vectors, time embedding and the target embedding (transformer_cfm.py:39-42,84-90,153-165), before the DMA pipeline starts
   for (int i = tid; i < a.nd * FD; i += 256) vbuf[i] = a.cv[((size_t)(i / FD) * a.B + b) * FD + (i % FD)];
-  for (int i = tid; i < FFF; i += 256) vbuf[4 * FD + i] = a.hv[(size_t)b * FFF + i];
   for (int i = tid; i < FL_MAX * LDF / 2; i += 256) reinterpret_cast<uint32_t*>(big)[i] = 0u;  // rows 48..63 of the q|k|v view are read as (zero-weighted) keys
+  float* gfp = red;             // [te] Fourier features, then [te] time embedding (red is free until the head's reduction)
+  float* tembs = red + 64;
+  if (tid < a.te) {             // same f32 operation order as the reference: ((t * W) * 2) * pi
+    const int half = a.te / 2;
+    float pr = a.t[b] * a.gfp_w[tid < half ? tid : tid - half];
+    pr = pr * 2.0f;
+    pr = pr * 3.14159265358979323846f;
+    gfp[tid] = tid < half ? sinf(pr) : cosf(pr);
+  }
+  __syncthreads();
+  {  // temb = W1 gfp + b1: 4 lanes per output
+    const int j = tid >> 2, q = tid & 3;
+    float sacc = 0.f;
+    if (j < a.te)
+      for (int k = q; k < a.te; k += 4) sacc += a.te_w[j * a.te + k] * gfp[k];
+    sacc += __shfl_xor(sacc, 1, 64);
+    sacc += __shfl_xor(sacc, 2, 64);
+    if (j < a.te && q == 0) tembs[j] = sacc + a.te_b[j];
+  }
+  __syncthreads();
+  for (int n = tid; n < FFF; n += 256) {  // head, time part: hv[n] = layer.weight[n, :te] . temb + layer.bias[n]
+    const float* wr = a.head_w + (size_t)n * (a.te + FD);
+    float sacc = a.head_b[n];
+    for (int k = 0; k < a.te; k += 4) {
+      const f32x4 wv = load4(wr + k);
+      sacc += wv[0] * tembs[k] + wv[1] * tembs[k + 1] + wv[2] * tembs[k + 2] + wv[3] * tembs[k + 3];
+    }
+    vbuf[4 * FD + n] = sacc;
+  }
   for (int i = tid; i < FL_MAX * FD; i += 256) {
     const int n = i / FD, j = i % FD;
     float v = 0.f;
-    if (n < L) v = j < a.te ? a.temb[(size_t)b * a.te + j] : a.x[(size_t)b * L + n] * a.wx[j - a.te] + a.bx[j - a.te] + a.pos[(size_t)n * (FD - a.te) + j - a.te];
+    if (n < L) v = j < a.te ? tembs[j] : a.x[(size_t)b * L + n] * a.wx[j - a.te] + a.bx[j - a.te] + a.pos[(size_t)n * (FD - a.te) + j - a.te];
     hres[i] = v;
     hT[n * LDH + j] = (bf16)v;
   }
@@ -374,15 +403,15 @@ int energy_fused_pack(const void* const* params, char* stream, int nd, int te, i
   V4H_CHECK_LAUNCH("energy_pack");
   return V4H_OK;
 }
-int energy_fused_decoder(const char* stream, const float* x, const float* temb, const float* wx, const float* bx, const float* pos, const float* cv, const float* hv,
-                         float* out, int B, int L, int nd, int te, hipStream_t s) {
+int energy_fused_decoder(const char* stream, const float* x, const float* t, const float* gfp_w, const float* te_w, const float* te_b, const float* wx, const float* bx,
+                         const float* pos, const float* cv, const float* head_w, const float* head_b, float* out, int B, int L, int nd, int te, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)energy_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
     if (e != hipSuccess) { v4h_set_error("energy_decoder: cannot reserve %zu bytes of LDS: %s", FUSED_LDS, hipGetErrorString(e)); return V4H_ERR_HIP; }
     attr_set = true;
   }
-  FusedArgs a{stream, x, temb, wx, bx, pos, cv, hv, out, B, L, nd, te};
+  FusedArgs a{stream, x, t, gfp_w, te_w, te_b, wx, bx, pos, cv, head_w, head_b, out, B, L, nd, te};
   hipLaunchKernelGGL(energy_decoder_kernel, dim3(B), dim3(256), FUSED_LDS, s, a);
   V4H_CHECK_LAUNCH("energy_decoder");
   return V4H_OK;

@@ -76,7 +76,7 @@ size_t energy_fused_stream_bytes(int nd);
 bool energy_fused_supported(int d, int ff, int H, int L, int nd, int te);
 int energy_fused_pack(const void* const* params, char* stream, int nd, int te, int dec0, int dcount, int dec_norm, int head_w, int head_b, int out_w, int out_b,
                       hipStream_t s);
-int energy_fused_decoder(const char* stream, const float* x, const float* temb, const float* wx, const float* bx, const float* pos, const float* cv, const float* hv,
-                         float* out, int B, int L, int nd, int te, hipStream_t s);
+int energy_fused_decoder(const char* stream, const float* x, const float* t, const float* gfp_w, const float* te_w, const float* te_b, const float* wx, const float* bx,
+                         const float* pos, const float* cv, const float* head_w, const float* head_b, float* out, int B, int L, int nd, int te, hipStream_t s);
 
 }  // namespace v4h
