@@ -210,3 +210,41 @@ def test_torch_optimizer_dropin_matches_native_trainer(golden):
         opt.step()
         sched.step()
         assert abs(loss.item() - g["train/losses"][k]) / g["train/losses"][k] < 1e-4
+
+
+def test_staged_backward_with_collectives_matches_single_call():
+    """The multi-rank code path on one GPU: process group of one rank (RCCL), per-stage backward calls each ending in a stream join,
+    bucketed all-reduce on the communication stream - must give what the single-call path gives."""
+    import os
+
+    import torch.distributed as dist
+
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    fill = O.golden_fill(cfg)
+    x, c, g = O.synthetic_batch(cfg, 4, 9)
+    noise = [O.synthetic_noise(cfg, 4, g) for _ in range(3)]
+    x, c = x.to(U.DEV), c.to(U.DEV)
+
+    def run():
+        model = U.build_models(cfg, "f32", fill)
+        tr = CFMTrainer(model, iterations=20)
+        out = [tr.step(x, c, t.to(U.DEV), x0.to(U.DEV)) for t, x0 in noise]
+        return [float(l) for l, _ in out], [float(n) for _, n in out], {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    l0, n0, w0 = run()
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    dist.init_process_group("nccl", init_method="env://", device_id=torch.device(U.DEV))
+    os.environ["V4H_FORCE_COLLECTIVES"] = "1"
+    try:
+        from vit4hep_amd.parallel import collectives_enabled
+
+        assert collectives_enabled()
+        l1, n1, w1 = run()
+    finally:
+        os.environ.pop("V4H_FORCE_COLLECTIVES", None)
+        dist.destroy_process_group()
+    assert np.allclose(l0, l1, rtol=1e-6) and np.allclose(n0, n1, rtol=1e-5)
+    for k in w0:  # small-batch conditioning tensors are accumulated with f32 atomics (order varies run to run), Adam normalises the difference
+        assert U.rel_err(w1[k], w0[k]) < 1e-4, k
