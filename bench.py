@@ -265,8 +265,9 @@ def main():
             "vs_baseline": None,
             "dtype": args.mode,
             "data": "synthetic",
-            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "tokens": T, "patch_dim": P, "depth": depth, "parallelism": f"dp{world}",
-                       "params": sum(p.numel() for p in model.parameters()), "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
+            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "details": {"tokens": T, "patch_dim": P, "depth": depth, "params": sum(p.numel() for p in model.parameters()),
+                        "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
             "loss": round(float(loss), 5),
             "grad_norm": round(float(gn), 5),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": MEASURED_HBM_BYTES_PER_STEP.get((args.workload, args.mode)),
