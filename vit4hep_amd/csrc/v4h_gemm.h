@@ -512,6 +512,20 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
 #pragma unroll
         for (int y = 0; y < C::TJ; ++y) acc[x][y] = mma(qf[y], pf[x], acc[x][y]);  // (s_setprio around the cluster measured 40 % slower here)
     }
+    if constexpr (C::DBG == 7 && sizeof(T) == 2 && C::BK == 64) {
+      // Scheduling experiment (tools/gemm_bench.py cfg 28): slab 0's fragment reads first, then slab 1's reads spread between slab 0's MFMAs,
+      // then the remaining MFMAs - two lgkmcnt waits per K-step instead of the compiler's four full drains.  Plain-store kernels gain
+      // (fc2 shape, K = 1920: +9 %; proj +4 %; qkv / fc1 and transposed-read operands: nothing), but the 18 live fragments push the
+      // fused-epilogue variants over the 256-register budget (GATE_RESID: 26 spills) and the sampler ran 6 % SLOWER end to end: not enabled.
+      constexpr int NR = C::TI * (C::PKS ? 2 : 1) + C::TJ * (C::QKS ? 2 : 1), NM = C::TI * C::TJ;
+      __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / NR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NM - (NM / NR) * NR, 0);
+    }
   };
   auto compute = [&](int buf) {  // one scalar branch per K-step, outside the MFMA cluster
     if constexpr (C::COLSUM) {

@@ -49,6 +49,7 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_
       case 18: if constexpr (!QKS) return v4h_gemm_launch<GemmCfg<T, T, false, false, 256, 240, 64, 4, 3, EPI_STORE, false>>(a, 1, s, name); else break;
       case 19: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 3, EPI_STORE, false>>(a, 1, s, name);
       case 22: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
+      case 28: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 7>>(a, 1, s, name);
       // (measured and removed: 112-row tiles - 465 instead of 405 tiles on the 512 slots for J = 480 - as 1 x 5 or 1 x 2 waves: 13-35 % slower)
       // (measured and removed: one 8-wave workgroup per CU with a 4-deep ring of BK = 64 slabs, 108 KB in flight: 25-40 % slower
       //  than two 4-wave workgroups with two slabs each - DESIGN.md section 5)
