@@ -217,3 +217,11 @@ def test_dropin_aliases_reference_module_paths():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def test_driver_build_entry_point():
+    """__graft_entry__.build(): compile (or reuse) the library, dlopen it, resolve every symbol, import every host class - on the CPU."""
+    import importlib
+
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
