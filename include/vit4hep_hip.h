@@ -122,6 +122,7 @@ size_t v4h_energy_plan_workspace_bytes(const v4h_energy_plan* plan, int32_t B);
  * decoder's cross-attention terms (functions of the condition only) are reused: the ODE solver calls the network 80 times per
  * batch with one condition (models/base_model.py:231-242). */
 #define V4H_ENERGY_SAME_CONDITION 4
+#define V4H_ENERGY_COMPOSED 8 /* run the kernel-per-operator path even where the one-launch resident decoder applies (tests, A/B measurements) */
 int32_t v4h_energy_forward(const v4h_energy_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
                            float* d_out, void* d_workspace, size_t workspace_bytes, int32_t flags, void* stream);
 

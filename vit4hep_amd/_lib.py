@@ -217,7 +217,7 @@ class Plan:
             pass
 
 
-FWD_TRAINING, FWD_REUSE_OPERANDS, ENERGY_SAME_CONDITION = 1, 2, 4  # flag bits of include/vit4hep_hip.h
+FWD_TRAINING, FWD_REUSE_OPERANDS, ENERGY_SAME_CONDITION, ENERGY_COMPOSED = 1, 2, 4, 8  # flag bits of include/vit4hep_hip.h
 
 
 class EnergyPlan:

@@ -269,7 +269,7 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
   V4H_CHECK_ARG(B > 0, "energy_forward: empty batch (B=%d)", B);
   V4H_CHECK_ARG(params && ws && x && t && cnd && out, "energy_forward: null argument");
   V4H_CHECK_ARG(((uintptr_t)ws % 256) == 0, "energy_forward: workspace must be 256-byte aligned");
-  V4H_CHECK_ARG((flags & ~(V4H_FWD_REUSE_OPERANDS | V4H_ENERGY_SAME_CONDITION)) == 0, "energy_forward: unknown flag bits 0x%x (the network is forward-only)", flags);
+  V4H_CHECK_ARG((flags & ~(V4H_FWD_REUSE_OPERANDS | V4H_ENERGY_SAME_CONDITION | V4H_ENERGY_COMPOSED)) == 0, "energy_forward: unknown flag bits 0x%x (the network is forward-only)", flags);
   V4H_CHECK_ARG(ws_bytes >= v4h_energy_plan_workspace_bytes(p, B), "energy_forward: workspace too small (%zu < %zu bytes)", ws_bytes, v4h_energy_plan_workspace_bytes(p, B));
   for (int i = 0; i < p->nparams(); ++i) V4H_CHECK_ARG(params[i] != nullptr && ((uintptr_t)params[i] % 16) == 0, "energy_forward: parameter %d null or not 16-byte aligned", i);
   using PL = v4h_energy_plan;
@@ -315,10 +315,9 @@ extern "C" int32_t v4h_energy_forward(const v4h_energy_plan* p, int32_t B, const
     return gemm_fwd(m, epi, a, s);
   };
 
-  // Resident decoder: time embedding, target embedding, all decoder layers and the head in one launch.  One workgroup per sample is bound
-  // by the latency of its weight stream (109 images, one barrier each: ~130 us per sample and CU), which wins while the batch leaves the
-  // composed path's contractions latency-bound too and loses once those fill the chip (batch 2048: 1.23 vs 1.08 ms per evaluation).
-  const bool fused = w.fstream && B <= 1024;
+  // Resident decoder (bf16 mode, the shipped widths): time embedding, target embedding, all decoder layers and the head of a sample in one
+  // workgroup, one launch per evaluation (csrc/v4h_energy_fused.hip).  The composed kernels below serve f32 mode and other widths.
+  const bool fused = w.fstream && !(flags & V4H_ENERGY_COMPOSED);
 
   // 1. time embedding (per evaluation)   transformer_cfm.py:39-42
   if (!fused) {

@@ -20,7 +20,7 @@
 namespace v4h {
 namespace {
 constexpr int FD = 128, FFF = 512, FL_MAX = 48, FH = 4;        // d_model, feed-forward, padded tokens, heads (head_dim 32)
-constexpr int IMG = 16384, NST = 3;                            // bytes per image, ring depth
+constexpr int IMG = 16384, NST = 5;                            // bytes per image, ring depth (4 images = 64 KiB in flight)
 constexpr int LDH = FD + 8, LDQ = 3 * FD + 8, LDF = FFF + 8;   // bf16 row strides (elements): +16 B keeps 16 rows on distinct banks
 constexpr int IMGS_PER_LAYER = 25, IMGS_HEAD = 9;
 // parameter image of a decoder layer (float offsets)
@@ -121,13 +121,16 @@ V4H_DEV Frag<bf16> wfrag(const char* img, int n0, int kk, int lane) {  // ImgKCo
 
 __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* hres = reinterpret_cast<float*>(smem);                                    // [48][128] f32 residual stream
-  bf16* hT = reinterpret_cast<bf16*>(smem + FL_MAX * FD * 4);                      // [48][LDH] operand copy of h; aliased by the attention output
+  // The f32 residual stream lives in REGISTERS, in the accumulator layout of the contractions (lane (c, g) of res[x][y]: token 16 x + c,
+  // features 32 wave + 16 y + 4 g + 0..3): the residual add is a register add, LayerNorm exchanges per-row partial sums through `stat`.
+  // That keeps 24 KB of LDS for two more weight images in flight.
+  bf16* hT = reinterpret_cast<bf16*>(smem);                                        // [48][LDH] operand copy of h; aliased by the attention output
   bf16* big = hT + FL_MAX * LDH;                                                   // q|k|v [48][LDQ], later the feed-forward hidden [48][LDF]
   char* ring = reinterpret_cast<char*>(big + FL_MAX * LDF);                        // NST images
   float* pbuf = reinterpret_cast<float*>(ring + NST * IMG);                        // parameter image of the current layer
   float* vbuf = pbuf + PB_COUNT;                                                   // cv (nd x 128) | hv (512)
   float* red = vbuf + 4 * FD + FFF;                                                // [4][48] head partial sums
+  float* stat = red + 4 * FL_MAX;                                                  // [2][4 waves][48 rows][sum, sum of squares]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c = lane & 15, g = lane >> 4;
@@ -166,13 +169,30 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
     }
     vbuf[4 * FD + n] = sacc;
   }
-  for (int i = tid; i < FL_MAX * FD; i += 256) {
-    const int n = i / FD, j = i % FD;
-    float v = 0.f;
-    if (n < L) v = j < a.te ? tembs[j] : a.x[(size_t)b * L + n] * a.wx[j - a.te] + a.bx[j - a.te] + a.pos[(size_t)n * (FD - a.te) + j - a.te];
-    hres[i] = v;
-    hT[n * LDH + j] = (bf16)v;
-  }
+  f32x4 res[3][2];
+  auto put_hT = [&]() {  // operand copy of the residual stream for the next contraction
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)res[x][y][r];
+        *reinterpret_cast<bf16x4*>(hT + (16 * x + c) * LDH + 32 * wave + 16 * y + 4 * g) = o;
+      }
+  };
+#pragma unroll
+  for (int x = 0; x < 3; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * x + c, j = 32 * wave + 16 * y + 4 * g + r;
+        float v = 0.f;
+        if (n < L) v = j < a.te ? tembs[j] : a.x[(size_t)b * L + n] * a.wx[j - a.te] + a.bx[j - a.te] + a.pos[(size_t)n * (FD - a.te) + j - a.te];
+        res[x][y][r] = v;
+      }
+  put_hT();
   __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the counted waits below see only the image DMAs
   __syncthreads();
 
@@ -187,8 +207,7 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
     }
     ++issued;  // counted even past the end so that the wait arithmetic stays uniform
   };
-  issue();
-  issue();
+  for (int q = 0; q < NST - 1; ++q) issue();
   int cur = 0;  // next image to consume
   // image `cur` has landed everywhere and the slot of image cur - 1 is free; then keep the ring full
   auto acquire = [&]() -> const char* {
@@ -228,23 +247,49 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
 #pragma unroll
       for (int y = 0; y < 2; ++y) f(16 * x + c, 32 * wave + 16 * y + 4 * g, acc[x][y]);
   };
-  // rows of hres: two chained LayerNorms (the second optionally after adding a per-sample vector); wave w takes rows w, w + 4, ...
+  // Up to two chained LayerNorms of the register-resident rows (the second optionally after adding a per-sample vector).  Per stage: every
+  // lane sums its 8 features per row, two shuffles finish the wave's 32 features, the four waves exchange (sum, sum of squares) through
+  // `stat` (double-buffered by stage parity: one barrier per stage).
+  int ln_parity = 0;
   auto layer_norms = [&](const float* g1, const float* b1, const float* add, const float* g2, const float* b2) {
-    for (int r = wave; r < L; r += 4) {
-      float v0 = hres[r * FD + lane], v1 = hres[r * FD + 64 + lane];
-      for (int st = 0; st < (g2 ? 2 : 1); ++st) {
-        const float* gg = st ? g2 : g1;
-        const float* bb = st ? b2 : b1;
-        if (st && add) { v0 += add[lane]; v1 += add[64 + lane]; }
-        const float mu = wave_sum(v0 + v1) * (1.0f / FD);
-        const float d0 = v0 - mu, d1 = v1 - mu;
-        const float rs = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * (1.0f / FD) + 1e-5f);
-        v0 = d0 * rs * gg[lane] + bb[lane];
-        v1 = d1 * rs * gg[64 + lane] + bb[64 + lane];
+    for (int st = 0; st < (g2 ? 2 : 1); ++st) {
+      const float* gg = st ? g2 : g1;
+      const float* bb = st ? b2 : b1;
+      float* sb = stat + ln_parity * (4 * FL_MAX * 2);
+      ln_parity ^= 1;
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (st && add) res[x][y][r] += add[32 * wave + 16 * y + 4 * g + r];
+            s1 += res[x][y][r];
+            s2 += res[x][y][r] * res[x][y][r];
+          }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (g == 0) { sb[(wave * FL_MAX + 16 * x + c) * 2] = s1; sb[(wave * FL_MAX + 16 * x + c) * 2 + 1] = s2; }
       }
-      hres[r * FD + lane] = v0; hres[r * FD + 64 + lane] = v1;
-      hT[r * LDH + lane] = (bf16)v0; hT[r * LDH + 64 + lane] = (bf16)v1;
+      wg_barrier();
+#pragma unroll
+      for (int x = 0; x < 3; ++x) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) { s1 += sb[(w2 * FL_MAX + 16 * x + c) * 2]; s2 += sb[(w2 * FL_MAX + 16 * x + c) * 2 + 1]; }
+        const float mu = s1 * (1.0f / FD);
+        const float rs = 1.0f / sqrtf(fmaxf(s2 * (1.0f / FD) - mu * mu, 0.0f) + 1e-5f);
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = 32 * wave + 16 * y + 4 * g + r;
+            res[x][y][r] = (res[x][y][r] - mu) * rs * gg[n] + bb[n];
+          }
+      }
     }
+    put_hT();
   };
 
   for (int layer = 0; layer < a.nd; ++layer) {
@@ -321,11 +366,13 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
     // ---- out_proj + residual, LayerNorm1, + cross-attention vector, LayerNorm2
     zero_acc();
     for (int kt = 0; kt < 2; ++kt) gemm_image(hT, LDH, 64 * kt, acquire());  // the barrier inside acquire() publishes the attention output
-    for_acc([&](int m, int n, f32x4 v) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hres[m * FD + n + r] += v[r] + pbuf[PB_OUT + n + r];
-    });
-    wg_barrier();
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[x][y][r] += acc[x][y][r] + pbuf[PB_OUT + 32 * wave + 16 * y + 4 * g + r];
+    wg_barrier();  // every wave is done reading the attention output (aliased by hT) before the LayerNorms rewrite hT
     layer_norms(pbuf + PB_N1W, pbuf + PB_N1B, vbuf + layer * FD, pbuf + PB_N2W, pbuf + PB_N2B);
     // ---- feed-forward: relu(linear1) -> hidden (aliases q|k|v), linear2 + residual, LayerNorm3
     for (int nb = 0; nb < 4; ++nb) {
@@ -341,11 +388,12 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
     }
     zero_acc();
     for (int kt = 0; kt < 8; ++kt) gemm_image(big, LDF, 64 * kt, acquire());  // first acquire(): barrier after the hidden activations
-    for_acc([&](int m, int n, f32x4 v) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hres[m * FD + n + r] += v[r] + pbuf[PB_L2 + n + r];
-    });
-    wg_barrier();
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[x][y][r] += acc[x][y][r] + pbuf[PB_L2 + 32 * wave + 16 * y + 4 * g + r];
     const bool last = layer == a.nd - 1;
     layer_norms(pbuf + PB_N3W, pbuf + PB_N3B, nullptr, last ? pbuf + PB_NFW : nullptr, pbuf + PB_NFB);
   }
@@ -379,8 +427,9 @@ __global__ __launch_bounds__(256, 1) void energy_decoder_kernel(const FusedArgs 
   if (tid < L) a.out[(size_t)b * L + tid] = red[tid] + red[FL_MAX + tid] + red[2 * FL_MAX + tid] + red[3 * FL_MAX + tid] + pbuf[PH_B2];
 }
 
-constexpr size_t FUSED_LDS = (size_t)FL_MAX * FD * 4 + (size_t)FL_MAX * LDH * 2 + (size_t)FL_MAX * LDF * 2 + (size_t)NST * IMG + (size_t)PB_COUNT * 4 +
-                             (size_t)(4 * FD + FFF) * 4 + (size_t)4 * FL_MAX * 4;
+constexpr size_t FUSED_LDS = (size_t)FL_MAX * LDH * 2 + (size_t)FL_MAX * LDF * 2 + (size_t)NST * IMG + (size_t)PB_COUNT * 4 + (size_t)(4 * FD + FFF) * 4 +
+                             (size_t)4 * FL_MAX * 4 + (size_t)2 * 4 * FL_MAX * 2 * 4;
+static_assert(FUSED_LDS <= 160 * 1024, "resident decoder must fit the 160 KiB of LDS");
 }  // namespace
 
 size_t energy_fused_stream_bytes(int nd) { return (size_t)(nd * IMGS_PER_LAYER + IMGS_HEAD) * IMG; }
