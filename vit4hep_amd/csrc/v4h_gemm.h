@@ -443,9 +443,18 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
   //    per tile (measured: as long as the whole K = 480 main loop).
   //  * split-K (wgrad): split z lives on XCD z % 8 and all output tiles of a split run together, so the token rows of
   //    the split are fetched once per XCD and shared by every output tile; one tile per workgroup.
-  const int nvirt = a.nz == 1 ? ((a.nti + 7) / 8) * 8 * a.ntj : a.nti * a.ntj * a.nz;
+  //  * fewer than 8 i-tiles (batch-row contractions: adaLN modulations, embedders): the i-tile -> XCD pinning would leave whole XCDs
+  //    idle (one i-tile = one XCD = 32 of 256 CUs), so output tiles are simply dealt round-robin over the XCDs.
+  const bool few_rows = a.nz == 1 && a.nti < 8;
+  const int nvirt = few_rows ? a.nti * a.ntj : (a.nz == 1 ? ((a.nti + 7) / 8) * 8 * a.ntj : a.nti * a.ntj * a.nz);
   auto decode = [&](int v, int& ti, int& tj, int& tz) -> bool {
     if (v >= nvirt) return false;
+    if (few_rows) {
+      ti = v % a.nti;
+      tj = v / a.nti;
+      tz = 0;
+      return true;
+    }
     if (a.nz == 1) {
       const int xcd = v & 7, slot = v >> 3;
       tj = slot % a.ntj;
@@ -726,7 +735,7 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
   a.nz = (a.K + klen - 1) / klen;
   a.nti = (a.I + C::BI - 1) / C::BI;
   a.ntj = (a.J + C::BJ - 1) / C::BJ;
-  long nblocks = a.nz == 1 ? (long)((a.nti + 7) / 8) * 8 * a.ntj : (long)a.nti * a.ntj * a.nz;
+  long nblocks = a.nz == 1 ? (a.nti < 8 ? (long)a.nti * a.ntj : (long)((a.nti + 7) / 8) * 8 * a.ntj) : (long)a.nti * a.ntj * a.nz;
   V4H_CHECK_ARG(nblocks < (1L << 31), "%s: grid too large", name);
   if (a.nz == 1) {  // persistent workgroups: as many as are co-resident (256 CUs x workgroups per CU by LDS), a multiple of 8
     const long per_cu = (160 * 1024) / (long)C::LDS_BYTES > 0 ? (160 * 1024) / (long)C::LDS_BYTES : 1;

@@ -35,6 +35,7 @@ struct v4h_plan {
   int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;
   int Px, Pxpad;  // input width of the x_embedder Linear: P, or x_embed_in behind an embedding mapper
   bool mapper() const { return cfg.x_embed_in > 0; }
+  int ldmod() const { return 6 * D * depth + 2 * D; }  // row stride of the modulation table: [block 0: 6 D | ... | block depth-1: 6 D | final layer: 2 D]
   int xmw() const { return nparams() - 2; }  // mapper weight / bias: the last two tensors
   int xmb() const { return nparams() - 1; }
   PatchGeom pg;
@@ -211,6 +212,8 @@ struct WS {
   char *xpm, *xmb_pad, *dxpre;   // embedding mapper (fine-tuning): gathered input patches, padded bias, gradient of the pre-activation
   float *xpre, *gxmw, *gxmb;
   float *pe, *ht_pre, *hc_pre, *cond, *modf, *meanf, *rstdf;
+  float *mod_all, *adaB;   // every adaLN modulation of the step in one table (B x ldmod); concatenated adaLN biases
+  char* adaW;              // concatenated operand copies of the adaLN weights (ldmod x D), bf16 mode: one contraction makes the whole table
   std::vector<float*> mod, X;
   std::vector<BlockWS> blk;
   // backward
@@ -241,8 +244,14 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   const size_t es = esize(p.mode);
   const size_t BT = (size_t)B * p.T, D = p.D, M = p.M;
   w.wop.assign(p.nparams(), nullptr);
+  w.adaW = p.mode == MODE_BF16 ? take((size_t)p.ldmod() * D * es) : nullptr;
+  w.adaB = (float*)take((size_t)p.ldmod() * 4);
+  if (w.adaW || !base) {
+    for (int i = 0; i < p.depth && p.mode == MODE_BF16; ++i) w.wop[p.blk(i, B_ADAW)] = base ? w.adaW + (size_t)i * 6 * D * D * es : (char*)1;
+    if (p.mode == MODE_BF16) w.wop[p.fin(F_ADAW)] = base ? w.adaW + (size_t)p.depth * 6 * D * D * es : (char*)1;
+  }
   for (int i = 0; i < p.nparams(); ++i) {
-    if (p.cols[i] == 0) continue;
+    if (p.cols[i] == 0 || w.wop[i]) continue;
     int rp = p.rows[i], cp = p.cols[i];
     bool padded = false;
     if (i == P_XW) { cp = p.Pxpad; padded = true; }
@@ -269,8 +278,9 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   w.cond = (float*)take((size_t)B * D * 4);
   w.silu_c = take((size_t)B * D * es);
   w.mod.resize(p.depth);
-  for (int i = 0; i < p.depth; ++i) w.mod[i] = (float*)take((size_t)B * 6 * D * 4);
-  w.modf = (float*)take((size_t)B * 2 * D * 4);
+  w.mod_all = (float*)take((size_t)B * p.ldmod() * 4);
+  for (int i = 0; i < p.depth; ++i) w.mod[i] = w.mod_all ? w.mod_all + (size_t)i * 6 * D : nullptr;
+  w.modf = w.mod_all ? w.mod_all + (size_t)p.depth * 6 * D : nullptr;
   const int nx = training ? p.depth + 1 : 2;
   w.X.resize(p.depth + 1);
   std::vector<float*> xs(nx);
@@ -429,6 +439,11 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
     }
     if (!reuse) items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
+    for (int i = 0; i <= p->depth && !reuse; ++i) {  // concatenated adaLN biases
+      const bool last = i == p->depth;
+      const int J = last ? 2 * D : 6 * D;
+      items.push_back(CastPadItem{c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB)), w.adaB + (size_t)i * 6 * D, 1, J, 1, J, 1});
+    }
     if (!reuse && p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
     items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
@@ -467,37 +482,44 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
   }
   // 9. every adaLN modulation of the step (nn/vit.py:323-330, 345-348)
-  for (int i = 0; i <= p->depth; ++i) {
-    const bool last = i == p->depth;
-    const int J = last ? 2 * D : 6 * D;
-    GemmArgs a = gargs(w.silu_c, D, c.W(last ? p->fin(F_ADAW) : p->blk(i, B_ADAW)), D, B, J, D);
-    a.e.out = last ? w.modf : w.mod[i]; a.e.ldo = J; a.e.bias = c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB));
+  const int ldm = p->ldmod();
+  if (w.adaW) {  // one contraction for the whole table: (B, D) x (ldmod, D)^T - seven launches of 18 workgroups each were pure launch latency
+    GemmArgs a = gargs(w.silu_c, D, w.adaW, D, B, ldm, D);
+    a.e.out = w.mod_all; a.e.ldo = ldm; a.e.bias = w.adaB;
     RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
+  } else {
+    for (int i = 0; i <= p->depth; ++i) {
+      const bool last = i == p->depth;
+      const int J = last ? 2 * D : 6 * D;
+      GemmArgs a = gargs(w.silu_c, D, c.W(last ? p->fin(F_ADAW) : p->blk(i, B_ADAW)), D, B, J, D);
+      a.e.out = last ? w.modf : w.mod[i]; a.e.ldo = ldm; a.e.bias = c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB));
+      RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
+    }
   }
   // 10. DiT blocks (nn/vit.py:327-333)
   for (int i = 0; i < p->depth; ++i) {
     const BlockWS& b = w.blk[i];
     const float* mod = w.mod[i];
-    RUN(ln_modulate_fwd(m, w.X[i], mod, mod + D, 6 * D, b.u1, b.mean1, b.rstd1, BT, T, D, c.s));
+    RUN(ln_modulate_fwd(m, w.X[i], mod, mod + D, ldm, b.u1, b.mean1, b.rstd1, BT, T, D, c.s));
     GemmArgs a = gargs(b.u1, D, c.W(p->blk(i, B_QKVW)), D, BT, 3 * D, D);
     a.e.out = b.qkv; a.e.ldo = 3 * D; a.e.bias = c.pf(p->blk(i, B_QKVB));
     RUN(gemm_fwd(m, EPI_STORE, a, c.s));
     RUN(attention_fwd(m, b.qkv, b.o, b.lse, B, T, p->H, p->DH, c.s));
     a = gargs(b.o, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
     a.e.out = b.x_mid; a.e.ldo = D; a.e.out2 = training ? b.y1 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_PROJB));
-    a.e.rowvec = mod + 2 * D; a.e.ld_rowvec = 6 * D; a.e.T = T; a.e.resid = w.X[i]; a.e.ld_resid = D;
+    a.e.rowvec = mod + 2 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = w.X[i]; a.e.ld_resid = D;
     RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
-    RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, 6 * D, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
+    RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, ldm, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
     a = gargs(b.u2, D, c.W(p->blk(i, B_FC1W)), D, BT, M, D);
     a.e.out = training ? b.hgrad : nullptr; a.e.ldo = M; a.e.out2 = b.h; a.e.ldo2 = M;  /* hgrad = gelu_tanh'(fc1 output), h = gelu_tanh(fc1 output) */ a.e.bias = c.pf(p->blk(i, B_FC1B));
     RUN(gemm_fwd(m, EPI_GELU, a, c.s));
     a = gargs(b.h, M, c.W(p->blk(i, B_FC2W)), M, BT, D, M);
     a.e.out = w.X[i + 1]; a.e.ldo = D; a.e.out2 = training ? b.y2 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_FC2B));
-    a.e.rowvec = mod + 5 * D; a.e.ld_rowvec = 6 * D; a.e.T = T; a.e.resid = b.x_mid; a.e.ld_resid = D;
+    a.e.rowvec = mod + 5 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = b.x_mid; a.e.ld_resid = D;
     RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
   }
   // 11. FinalLayer (nn/vit.py:347-351) with from_patches fused into the store
-  RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, 2 * D, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
+  RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, ldm, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
   {
     GemmArgs a = gargs(w.uf, D, c.W(p->fin(F_LINW)), D, BT, p->Ppad, D);
     a.e.out = out; a.e.bias = w.linb_pad; a.e.T = T; a.e.pg = p->pg; a.e.P = p->P; a.e.map = pmap; a.e.V = p->V;
@@ -548,9 +570,9 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
-      l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = 2 * D;
+      l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = p->ldmod();
       l.dx_out = dxbuf(0); l.dshift = w.dmodf; l.dscale = w.dmodf + D; l.ld_dmod = 2 * D;
-      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[depth - 1] + 5 * D; l.ld_dgate = 6 * D;
+      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = w.dmod[depth - 1] + 5 * D; l.ld_dgate = 6 * D;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       RUN(unpad_f32(w.glin, D, (float*)grads[p->fin(F_LINW)], p->P, D, c.s));
@@ -583,9 +605,9 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       if (prev) RUN(main_wait_mark(*p, S_PROJ, c.s));  // dy2 is about to be overwritten
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
-      l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = 6 * D;
+      l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = p->ldmod();
       l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = w.dmod[i] + 3 * D; l.dscale = w.dmod[i] + 4 * D; l.ld_dmod = 6 * D;
-      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy2; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
+      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy2; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
@@ -605,11 +627,11 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
       if (ov) RUN(main_wait_mark(*p, S_FC2, c.s));  // dy (read by this block's fc2 weight gradient, first in the side queue) is about to be overwritten
       memset(&l, 0, sizeof(l));
-      l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = 6 * D;
+      l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = p->ldmod();
       l.dx_in = dx_mid; l.dshift = w.dmod[i]; l.dscale = w.dmod[i] + D; l.ld_dmod = 6 * D;
       if (i > 0) {
         l.dx_out = dx_out;
-        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = 6 * D; l.dy = w.dy; l.dgate = w.dmod[i - 1] + 5 * D; l.ld_dgate = 6 * D;
+        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = w.dmod[i - 1] + 5 * D; l.ld_dgate = 6 * D;
       } else {
         l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
       }
