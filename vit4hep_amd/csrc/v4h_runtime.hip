@@ -529,15 +529,22 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// Backward of one adaLN Linear: weight / bias gradients and the contribution to d silu(cond).  Nothing on the main stream needs these
+// before the embedder stage, so the three small launches (batch-row contractions: pure latency) run on the weight-gradient stream.
 static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int bidx, void* const* grads) {
   const WS& w = c.w;
   const int D = c.p.D, B = c.B;
+  hipStream_t st = c.s;
+  if (g_overlap_wgrad) {
+    RUN(side_wait_main(c.p, c.s));  // dmod complete
+    st = c.p.side;
+  }
   CastPadItem it{dmod, w.dmod_t, B, J, B, J, 0};
-  RUN(cast_pad_many(c.p.mode, &it, 1, c.s));
-  RUN(wgrad(c, w.dmod_t, J, J, w.silu_c, D, D, B, (float*)grads[widx], D, (float*)grads[bidx]));
+  RUN(cast_pad_many(c.p.mode, &it, 1, st));
+  RUN(wgrad(c, w.dmod_t, J, J, w.silu_c, D, D, B, (float*)grads[widx], D, (float*)grads[bidx], st));
   GemmArgs a = gargs(w.dmod_t, J, c.W(widx), D, B, D, J);  // M = B rows only: spread the long K over the chip instead
   a.e.out = w.dsilu; a.e.ldo = D;
-  return gemm_dgrad(c.p.mode, EPI_ATOMIC_F32, a, c.s, J / 96);
+  return gemm_dgrad(c.p.mode, EPI_ATOMIC_F32, a, st, J / 96);
 }
 
 extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
@@ -652,6 +659,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       }
       if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
       else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
+      if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
       // c_embedder
       RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
