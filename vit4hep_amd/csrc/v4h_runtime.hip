@@ -50,7 +50,7 @@ struct v4h_plan {
   // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev[8] = {};
-  mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block)
+  mutable hipEvent_t evS[5] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable int evi = 0;
   mutable bool side_ok = false;
 };
@@ -73,7 +73,7 @@ static int side_init(const v4h_plan& p) {
   if (se != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 5; ++i)
     if (hipEventCreateWithFlags(&p.evS[i], hipEventDisableTiming) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   p.side_ok = true;
   return V4H_OK;
@@ -96,7 +96,7 @@ static int main_wait_side(const v4h_plan& p, hipStream_t main) {
 // stream's tail + the cross-stream signal latency, measured 7-13 us each, 12 per step), the side stream drops a mark after each
 // weight gradient and the main stream waits for the mark just before the NEXT write of that buffer - half a block to a full
 // block later, when the mark has normally long been reached.
-enum { S_FC2 = 0, S_FC1, S_PROJ, S_QKV };
+enum { S_FC2 = 0, S_FC1, S_PROJ, S_QKV, S_ADA };
 static int side_mark(const v4h_plan& p, int which) {
   if (hipEventRecord(p.evS[which], p.side) != hipSuccess) { v4h_set_error("mark failed"); return V4H_ERR_HIP; }
   return V4H_OK;
@@ -221,7 +221,7 @@ struct WS {
   std::vector<float*> dmod;
   float *dmodf, *dsilu, *gxw, *gc0w, *glin, *glinb;
   float *dxA, *dxB, *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
-  char *dvp, *dy, *dy2, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
+  char *dvp, *dy, *dy2, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dh_small2, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
   size_t total;
 };
 
@@ -335,6 +335,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     w.dmod_t = take((size_t)B * 6 * D * es);
     w.dcond = take((size_t)B * D * es);
     w.dh_small = take((size_t)B * D * es);
+    w.dh_small2 = take((size_t)B * D * es);
     w.dx0_t = take(BT * D * es);
   }
   w.total = off;
@@ -448,6 +449,12 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
+  // The token path (to_patches, positional table, x_embedder) and the conditioning path (t/c embedders, adaLN table) are
+  // independent chains of small launch-latency-bound kernels until the first block: they run side by side.
+  RUN(side_init(*p));
+  const bool fork = g_overlap_wgrad;
+  hipStream_t cs = c.s;  // stream of the conditioning path
+  if (fork) { RUN(side_wait_main(*p, c.s)); cs = p->side; }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
   char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
   if (pmap) RUN(patchify_map(m, false, x, pmap, patches, B, p->V, T, p->P, p->Ppad, c.s));
@@ -466,36 +473,37 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     RUN(gemm_fwd(m, EPI_EMBED, a, c.s));
   }
   // 4-8. t_embedder, c_embedder, cond = t_emb + c_emb, silu(cond) (nn/vit.py:197-199)
-  RUN(timestep_embed(m, t, w.temb, B, p->F, c.s));
+  RUN(timestep_embed(m, t, w.temb, B, p->F, cs));
   {
     GemmArgs a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
     a.e.out = w.ht; a.e.ldo = D; a.e.out2 = w.ht_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_T0B);
-    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+    RUN(gemm_fwd(m, EPI_SILU, a, cs));
     a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
     a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B);
-    RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
+    RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
     a = gargs(w.cpad, p->Kcpad, c.W(P_C0W), p->Kcpad, B, D, p->Kcpad);
     a.e.out = w.hc; a.e.ldo = D; a.e.out2 = w.hc_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_C0B);
-    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+    RUN(gemm_fwd(m, EPI_SILU, a, cs));
     a = gargs(w.hc, D, c.W(P_C2W), D, B, D, D);
     a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B); a.e.resid = w.cond; a.e.ld_resid = D;
-    RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
+    RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
   }
   // 9. every adaLN modulation of the step (nn/vit.py:323-330, 345-348)
   const int ldm = p->ldmod();
   if (w.adaW) {  // one contraction for the whole table: (B, D) x (ldmod, D)^T - seven launches of 18 workgroups each were pure launch latency
     GemmArgs a = gargs(w.silu_c, D, w.adaW, D, B, ldm, D);
     a.e.out = w.mod_all; a.e.ldo = ldm; a.e.bias = w.adaB;
-    RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
+    RUN(gemm_fwd(m, EPI_STORE_F32, a, cs));
   } else {
     for (int i = 0; i <= p->depth; ++i) {
       const bool last = i == p->depth;
       const int J = last ? 2 * D : 6 * D;
       GemmArgs a = gargs(w.silu_c, D, c.W(last ? p->fin(F_ADAW) : p->blk(i, B_ADAW)), D, B, J, D);
       a.e.out = last ? w.modf : w.mod[i]; a.e.ldo = ldm; a.e.bias = c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB));
-      RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
+      RUN(gemm_fwd(m, EPI_STORE_F32, a, cs));
     }
   }
+  if (fork) RUN(main_wait_side(*p, c.s));
   // 10. DiT blocks (nn/vit.py:327-333)
   for (int i = 0; i < p->depth; ++i) {
     const BlockWS& b = w.blk[i];
@@ -544,7 +552,9 @@ static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int 
   RUN(wgrad(c, w.dmod_t, J, J, w.silu_c, D, D, B, (float*)grads[widx], D, (float*)grads[bidx], st));
   GemmArgs a = gargs(w.dmod_t, J, c.W(widx), D, B, D, J);  // M = B rows only: spread the long K over the chip instead
   a.e.out = w.dsilu; a.e.ldo = D;
-  return gemm_dgrad(c.p.mode, EPI_ATOMIC_F32, a, st, J / 96);
+  RUN(gemm_dgrad(c.p.mode, EPI_ATOMIC_F32, a, st, J / 96));
+  if (g_overlap_wgrad) RUN(side_mark(c.p, S_ADA));  // d silu(cond) holds every contribution up to this block
+  return V4H_OK;
 }
 
 extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
@@ -571,7 +581,12 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       if (e != hipSuccess) { v4h_set_error("vit_backward: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
       if (pmap) RUN(patchify_map(m, false, dout, pmap, w.dvp, B, p->V, T, p->P, p->Ppad, c.s));
       else RUN(patchify(m, dout, w.dvp, B, p->pg, p->P, p->Ppad, c.s));
-      RUN(wgrad(c, w.dvp, p->Ppad, p->Ppad, w.uf, D, D, BT, w.glin, D, w.glinb));
+      const bool ov0 = g_overlap_wgrad;
+      hipStream_t s0 = ov0 ? p->side : c.s;
+      if (ov0) RUN(side_wait_main(*p, c.s));  // dvp ready, accumulators zeroed
+      RUN(wgrad(c, w.dvp, p->Ppad, p->Ppad, w.uf, D, D, BT, w.glin, D, w.glinb, s0));
+      RUN(unpad_f32(w.glin, D, (float*)grads[p->fin(F_LINW)], p->P, D, s0));
+      RUN(unpad_f32(w.glinb, 1, (float*)grads[p->fin(F_LINB)], p->P, 1, s0));
       GemmArgs a = gargs(w.dvp, p->Ppad, c.W(p->fin(F_LINW)), D, BT, D, p->Ppad);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
@@ -582,8 +597,6 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = w.dmod[depth - 1] + 5 * D; l.ld_dgate = 6 * D;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
-      RUN(unpad_f32(w.glin, D, (float*)grads[p->fin(F_LINW)], p->P, D, c.s));
-      RUN(unpad_f32(w.glinb, 1, (float*)grads[p->fin(F_LINB)], p->P, 1, c.s));
       RUN(adaln_backward(c, w.dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
     } else if (st <= depth) {
       const int j = st - 1, i = depth - 1 - j;
@@ -647,38 +660,44 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       RUN(adaln_backward(c, w.dmod[i], 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
     } else {
       // --- embedders (nn/vit.py:76-82,193-199) ---
-      RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Pxpad, p->Pxpad, BT, w.gxw, p->Pxpad, (float*)grads[P_XB]));
-      RUN(unpad_f32(w.gxw, p->Pxpad, (float*)grads[P_XW], D, p->Px, c.s));
+      // Three independent chains of small launches: x_embedder (+ mapper, positional table), c_embedder, t_embedder.  The first and the
+      // last run on the side stream, the c_embedder chain on the main stream.
+      const bool ov = g_overlap_wgrad;
+      hipStream_t sx = ov ? p->side : c.s;
+      if (ov) RUN(side_wait_main(*p, c.s));  // d x0 ready
+      RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Pxpad, p->Pxpad, BT, w.gxw, p->Pxpad, (float*)grads[P_XB], sx));
+      RUN(unpad_f32(w.gxw, p->Pxpad, (float*)grads[P_XW], D, p->Px, sx));
       if (p->mapper()) {  // d pre = (d x0 . Wx) * silu'(pre) ; d Wm = d pre^T patches ; d bm = column sums
         GemmArgs a = gargs(w.dx0_t, D, c.W(P_XW), p->Pxpad, BT, p->Pxpad, D);
         a.e.out = w.dxpre; a.e.ldo = p->Pxpad; a.e.auxf = w.xpre; a.e.ld_auxf = p->Pxpad;
-        RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
-        RUN(wgrad(c, w.dxpre, p->Pxpad, p->Pxpad, w.xpm, p->Ppad, p->Ppad, BT, w.gxmw, p->Ppad, w.gxmb));
-        RUN(unpad_f32(w.gxmw, p->Ppad, (float*)grads[p->xmw()], p->Px, p->P, c.s));
-        RUN(unpad_f32(w.gxmb, 1, (float*)grads[p->xmb()], p->Px, 1, c.s));
+        RUN(gemm_dgrad(m, EPI_DSILU, a, sx));
+        RUN(wgrad(c, w.dxpre, p->Pxpad, p->Pxpad, w.xpm, p->Ppad, p->Ppad, BT, w.gxmw, p->Ppad, w.gxmb, sx));
+        RUN(unpad_f32(w.gxmw, p->Ppad, (float*)grads[p->xmw()], p->Px, p->P, sx));
+        RUN(unpad_f32(w.gxmb, 1, (float*)grads[p->xmb()], p->Px, 1, sx));
       }
-      if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
-      else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
-      if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
+      if (ov) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
+      if (ov) RUN(side_wait_main(*p, c.s));  // d cond ready
+      // t_embedder
+      RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B], sx));
+      GemmArgs a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
+      a.e.out = w.dh_small2; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
+      RUN(gemm_dgrad(m, EPI_DSILU, a, sx));
+      RUN(wgrad(c, w.dh_small2, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B], sx));
       // c_embedder
       RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
-      GemmArgs a = gargs(w.dcond, D, c.W(P_C2W), D, B, D, D);
+      a = gargs(w.dcond, D, c.W(P_C2W), D, B, D, D);
       a.e.out = w.dh_small; a.e.ldo = D; a.e.auxf = w.hc_pre; a.e.ld_auxf = D;
       RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
       RUN(wgrad(c, w.dh_small, D, D, w.cpad, p->Kcpad, p->Kcpad, B, w.gc0w, p->Kcpad, (float*)grads[P_C0B]));
       RUN(unpad_f32(w.gc0w, p->Kcpad, (float*)grads[P_C0W], D, p->Kc, c.s));
-      // t_embedder
-      RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B]));
-      a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
-      a.e.out = w.dh_small; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
-      RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
-      RUN(wgrad(c, w.dh_small, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B]));
+      if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
+      else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
     }
   }
   // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
   // kernel is left reading a temporary the next call may overwrite.
-  if (g_overlap_wgrad && stage_last >= 1 && stage_first <= depth) RUN(main_wait_side(*p, c.s));
+  if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));
   return V4H_OK;
 }
 
