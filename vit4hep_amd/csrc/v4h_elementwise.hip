@@ -499,6 +499,16 @@ int cast_pad_many(Mode m, const CastPadItem* items, int n, hipStream_t s) {
   }
   return V4H_OK;
 }
+namespace {
+__global__ void write_ptr_table_kernel(PtrTable t, float** dst) {
+  if (threadIdx.x < 2 * V4H_GEMM_MAX_GROUPS) dst[threadIdx.x] = t.p[threadIdx.x];
+}
+}  // namespace
+int write_ptr_table(const PtrTable& t, float** dst, hipStream_t s) {
+  hipLaunchKernelGGL(write_ptr_table_kernel, dim3(1), dim3(2 * V4H_GEMM_MAX_GROUPS), 0, s, t, dst);
+  V4H_CHECK_LAUNCH("write_ptr_table");
+  return V4H_OK;
+}
 int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_t s) {
   hipLaunchKernelGGL(unpad_kernel, dim3((R * C + 255) / 256), dim3(256), 0, s, src, ld_src, dst, R, C);
   V4H_CHECK_LAUNCH("unpad");

@@ -44,6 +44,7 @@ struct PatchGeom {  // CaloChallengeCFM.to_patches / from_patches  (calochalleng
   int l, a, r;      // patches per axis
 };
 
+constexpr int V4H_GEMM_MAX_GROUPS = 64;
 struct EpiArgs {
   void* out; int ldo;
   void* out2; int ldo2;
@@ -56,6 +57,12 @@ struct EpiArgs {
   PatchGeom pg; int P;                  // EPI_UNPATCH: real patch_dim (columns >= P are padding)
   long slab_stride;                     // EPI_SLAB_F32: elements between the partial results of consecutive K splits
   const int* map; long V;               // EPI_UNPATCH, mapped geometry: voxel index of (token n, feature f) = map[n*P + f] (or -1), V voxels per sample
+  // EPI_ATOMIC_F32, grouped output: rows [g * group_rows, (g+1) * group_rows) of the result go to the tensor group_tab[g] (its row 0) and
+  // their column sums to group_tab[V4H_GEMM_MAX_GROUPS + g] - one launch for several tensors that share the Q operand (all adaLN weight
+  // gradients of a step).  group_tab is a DEVICE table (kernel arguments stay small: 1 KB more of them cost 2 % of the step in launch
+  // overhead); group_rows must be a multiple of 16; 0 = off.
+  int group_rows;
+  float* const* group_tab;
 };
 
 struct GemmArgs {
@@ -627,16 +634,20 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
     constexpr int SLD = C::WTJ + 4;
     static_assert(C::NW * 16 * SLD * sizeof(float) <= C::LDS_BYTES, "atomic staging strip must fit the operand LDS");
     float* strip = reinterpret_cast<float*>(smem) + wave * (16 * SLD);  // no prefetch in flight on this path
-    float* outp = reinterpret_cast<float*>(a.e.out);
 #pragma unroll
     for (int x = 0; x < C::TI; ++x) {
 #pragma unroll
       for (int y = 0; y < C::TJ; ++y) *reinterpret_cast<f32x4*>(strip + c * SLD + y * 16 + 4 * g) = acc[x][y];
       __syncthreads();
       const int ib = i0 + wi * C::WTI + x * 16, jb = j0 + wj * C::WTJ;
+      float* outp = reinterpret_cast<float*>(a.e.out) + (size_t)ib * a.e.ldo;  // row ib of the output
+      if (a.e.group_rows > 0 && ib < a.I) {
+        const int gi = ib / a.e.group_rows;  // a 16-row strip never straddles two groups
+        outp = a.e.group_tab[gi] + (size_t)(ib - gi * a.e.group_rows) * a.e.ldo;
+      }
       for (int id = lane; id < 16 * C::WTJ; id += 64) {
         const int row = id / C::WTJ, col = id % C::WTJ;
-        if (ib + row < a.I && jb + col < a.J) atomicAdd(outp + (size_t)(ib + row) * a.e.ldo + jb + col, strip[row * SLD + col]);
+        if (ib + row < a.I && jb + col < a.J) atomicAdd(outp + (size_t)row * a.e.ldo + jb + col, strip[row * SLD + col]);
       }
       __syncthreads();
     }
@@ -712,7 +723,9 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
         const int i = i0 + wi * C::WTI + x * 16 + c;
-        if (g == 0 && i < a.I) atomicAdd(a.colsum + i, s);
+        float* dst = a.colsum + i;
+        if (C::EPI == EPI_ATOMIC_F32 && a.e.group_rows > 0 && i < a.I) dst = a.e.group_tab[V4H_GEMM_MAX_GROUPS + i / a.e.group_rows] + i % a.e.group_rows;
+        if (g == 0 && i < a.I) atomicAdd(dst, s);
       }
     }
   }

@@ -25,6 +25,8 @@ int attention_bwd(Mode m, const void* qkv, const void* o, const void* dout, cons
 // ---- element-wise / reductions (v4h_elementwise.hip) ----
 struct CastPadItem { const float* src; void* dst; int R, C, Rp, Cp; int dst_f32; };  // dst[Rp][Cp] (mode type, or f32 if dst_f32) <- zero-padded src[R][C]
 int cast_pad_many(Mode m, const CastPadItem* items, int n, hipStream_t s);
+struct PtrTable { float* p[2 * V4H_GEMM_MAX_GROUPS]; };
+int write_ptr_table(const PtrTable& t, float** dst, hipStream_t s);                      // dst[k] = t.p[k]: a small device table filled from kernel arguments
 int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_t s);   // dst[R][C] += src[r][c]
 
 int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s);

@@ -56,10 +56,13 @@ struct v4h_plan {
 };
 
 static bool g_overlap_wgrad = true;  // V4H_WGRAD_OVERLAP=0 disables the side stream
+static bool g_batch_adaln = true;    // V4H_BATCH_ADALN=0: per-block adaLN backward also in single-call passes (A/B hook)
 static int side_init(const v4h_plan& p) {
   if (p.side_ok) return V4H_OK;
   const char* e = getenv("V4H_WGRAD_OVERLAP");
   if (e && e[0] == '0') g_overlap_wgrad = false;
+  e = getenv("V4H_BATCH_ADALN");
+  if (e && e[0] == '0') g_batch_adaln = false;
   // HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4); two streams that land on the same queue run
   // their kernels back to back.  Measured: after torch.distributed + a communication stream exist, a plain side stream shares the
   // main stream's queue and ALL overlap is lost (144.8 vs 166.9 steps/s).  Streams of another priority class get their own queue.
@@ -224,8 +227,9 @@ struct WS {
   std::vector<BlockWS> blk;
   // backward
   char* zero_begin; size_t zero_bytes;
-  std::vector<float*> dmod;
-  float *dmodf, *dsilu, *gxw, *gc0w, *glin, *glinb;
+  float* dmod_base;
+  float** gtab;  // device table of the grouped adaLN weight-gradient contraction
+  float *dsilu, *gxw, *gc0w, *glin, *glinb;
   float *dxA, *dxB, *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
   char *dvp, *dy, *dy2, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dh_small2, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
   size_t total;
@@ -311,9 +315,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   if (training) {
     w.zero_begin = base ? base + off : nullptr;
     const size_t z0 = off;
-    w.dmod.resize(p.depth);
-    for (int i = 0; i < p.depth; ++i) w.dmod[i] = (float*)take((size_t)B * 6 * D * 4);
-    w.dmodf = (float*)take((size_t)B * 2 * D * 4);
+    w.dmod_base = (float*)take((size_t)B * p.ldmod() * 4);  // d modulation of every block + final layer; strides chosen per backward pass
     w.dsilu = (float*)take((size_t)B * D * 4);
     w.gxw = (float*)take((size_t)D * p.Pxpad * 4);
     w.dxpre = nullptr; w.gxmw = nullptr; w.gxmb = nullptr;
@@ -338,7 +340,8 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     w.du = take(BT * D * es);
     w.dof = take(BT * D * es);
     w.dqkv = take(BT * 3 * D * es);
-    w.dmod_t = take((size_t)B * 6 * D * es);
+    w.dmod_t = take((size_t)B * p.ldmod() * es);
+    w.gtab = (float**)take(sizeof(PtrTable));
     w.dcond = take((size_t)B * D * es);
     w.dh_small = take((size_t)B * D * es);
     w.dh_small2 = take((size_t)B * D * es);
@@ -580,6 +583,15 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
   RUN(side_init(*p));
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
   auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
+  // A backward pass issued as ONE call handles every adaLN Linear of the step together at the end (one cast, one grouped weight-gradient
+  // contraction, one contraction for d silu(cond)) instead of three latency-bound launches per block: the d-modulation buffer is then one
+  // (B, ldmod) table like the forward's.  Staged passes (gradient buckets reduced while later stages run) need each block's adaLN
+  // gradients final at the end of its stage and keep the per-block launches, with per-block (B, 6 D) buffers in the same memory.
+  const int ldm = p->ldmod();
+  const bool batch_ada = g_batch_adaln && stage_first == 0 && stage_last == depth + 1 && w.adaW != nullptr && 3 * depth + 1 <= V4H_GEMM_MAX_GROUPS && D % 8 == 0;
+  const int ldd = batch_ada ? ldm : 6 * D, lddf = batch_ada ? ldm : 2 * D;
+  auto dmod = [&](int i) { return w.dmod_base + (batch_ada ? (size_t)i * 6 * D : (size_t)i * B * 6 * D); };
+  float* const dmodf = dmod(depth);
 
   for (int st = stage_first; st <= stage_last; ++st) {
     if (st == 0) {
@@ -599,11 +611,11 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = p->ldmod();
-      l.dx_out = dxbuf(0); l.dshift = w.dmodf; l.dscale = w.dmodf + D; l.ld_dmod = 2 * D;
-      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = w.dmod[depth - 1] + 5 * D; l.ld_dgate = 6 * D;
+      l.dx_out = dxbuf(0); l.dshift = dmodf; l.dscale = dmodf + D; l.ld_dmod = lddf;
+      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = dmod(depth - 1) + 5 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
-      RUN(adaln_backward(c, w.dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
+      if (!batch_ada) RUN(adaln_backward(c, dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
     } else if (st <= depth) {
       const int j = st - 1, i = depth - 1 - j;
       const BlockWS& b = w.blk[i];
@@ -632,8 +644,8 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = p->ldmod();
-      l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = w.dmod[i] + 3 * D; l.dscale = w.dmod[i] + 4 * D; l.ld_dmod = 6 * D;
-      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy2; l.dgate = w.dmod[i] + 2 * D; l.ld_dgate = 6 * D;
+      l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = dmod(i) + 3 * D; l.dscale = dmod(i) + 4 * D; l.ld_dmod = ldd;
+      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy2; l.dgate = dmod(i) + 2 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
@@ -654,23 +666,49 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       if (ov) RUN(main_wait_mark(*p, S_FC2, c.s));  // dy (read by this block's fc2 weight gradient, first in the side queue) is about to be overwritten
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = p->ldmod();
-      l.dx_in = dx_mid; l.dshift = w.dmod[i]; l.dscale = w.dmod[i] + D; l.ld_dmod = 6 * D;
+      l.dx_in = dx_mid; l.dshift = dmod(i); l.dscale = dmod(i) + D; l.ld_dmod = ldd;
       if (i > 0) {
         l.dx_out = dx_out;
-        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = w.dmod[i - 1] + 5 * D; l.ld_dgate = 6 * D;
+        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = dmod(i - 1) + 5 * D; l.ld_dgate = ldd;
       } else {
         l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
       }
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
-      RUN(adaln_backward(c, w.dmod[i], 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
+      if (!batch_ada) RUN(adaln_backward(c, dmod(i), 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
     } else {
       // --- embedders (nn/vit.py:76-82,193-199) ---
       // Three independent chains of small launches: x_embedder (+ mapper, positional table), c_embedder, t_embedder.  The first and the
       // last run on the side stream, the c_embedder chain on the main stream.
       const bool ov = g_overlap_wgrad;
       hipStream_t sx = ov ? p->side : c.s;
-      if (ov) RUN(side_wait_main(*p, c.s));  // d x0 ready
+      if (batch_ada) {
+        CastPadItem it{w.dmod_base, w.dmod_t, B, ldm, B, ldm, 0};
+        RUN(cast_pad_many(m, &it, 1, c.s));
+      }
+      if (ov) RUN(side_wait_main(*p, c.s));  // d x0 (and the operand copy of d modulation) ready
+      if (batch_ada) {
+        // d silu(cond) = d mod . W_ada over K = ldmod, spread over the chip in K (M is only B rows): needed by the main stream next
+        GemmArgs a = gargs(w.dmod_t, ldm, w.adaW, D, B, D, ldm);
+        a.e.out = w.dsilu; a.e.ldo = D;
+        RUN(gemm_dgrad(m, EPI_ATOMIC_F32, a, c.s, (ldm + 255) / 256));
+        // every adaLN weight / bias gradient in one contraction: groups of 2 D rows (block i = groups 3i..3i+2, final layer = the last one)
+        a = gargs(w.dmod_t, ldm, w.silu_c, D, ldm, D, B);
+        a.e.ldo = D; a.e.group_rows = 2 * D;
+        PtrTable tab;
+        memset(&tab, 0, sizeof(tab));
+        for (int i = 0; i <= depth; ++i) {
+          float* gw = (float*)grads[i < depth ? p->blk(i, B_ADAW) : p->fin(F_ADAW)];
+          float* gb = (float*)grads[i < depth ? p->blk(i, B_ADAB) : p->fin(F_ADAB)];
+          for (int k = 0; k < (i < depth ? 3 : 1); ++k) {
+            tab.p[3 * i + k] = gw + (size_t)k * 2 * D * D;
+            tab.p[V4H_GEMM_MAX_GROUPS + 3 * i + k] = gb + (size_t)k * 2 * D;
+          }
+        }
+        RUN(write_ptr_table(tab, w.gtab, sx));  // the gradient tensors may move between calls: the table is rewritten every time
+        a.e.group_tab = w.gtab; a.e.out = tab.p[0]; a.colsum = tab.p[V4H_GEMM_MAX_GROUPS];
+        RUN(gemm_wgrad(m, a, 1, sx));
+      }
       RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Pxpad, p->Pxpad, BT, w.gxw, p->Pxpad, (float*)grads[P_XB], sx));
       RUN(unpad_f32(w.gxw, p->Pxpad, (float*)grads[P_XW], D, p->Px, sx));
       if (p->mapper()) {  // d pre = (d x0 . Wx) * silu'(pre) ; d Wm = d pre^T patches ; d bm = column sums
@@ -681,7 +719,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
         RUN(unpad_f32(w.gxmw, p->Ppad, (float*)grads[p->xmw()], p->Px, p->P, sx));
         RUN(unpad_f32(w.gxmb, 1, (float*)grads[p->xmb()], p->Px, 1, sx));
       }
-      if (ov) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
+      if (ov && !batch_ada) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
       if (ov) RUN(side_wait_main(*p, c.s));  // d cond ready
       // t_embedder
