@@ -50,7 +50,7 @@ struct v4h_plan {
   // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev[8] = {};
-  mutable hipEvent_t evS[5] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
+  mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable int evi = 0;
   mutable bool side_ok = false;
 };
@@ -82,7 +82,7 @@ static int side_init(const v4h_plan& p) {
   if (ef && ef[0] == '1') evflags = hipEventDisableTiming;
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&p.ev[i], evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&p.evS[i], evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   p.side_ok = true;
   return V4H_OK;
@@ -100,12 +100,12 @@ static int main_wait_side(const v4h_plan& p, hipStream_t main) {
   return V4H_OK;
 }
 
-// Lagged joins.  The weight-gradient stream only READS the backward temporaries (dy, dhpre, dqkv); the main stream must not
-// overwrite one before its reader has finished.  Instead of joining the streams at every such point (main stalls for the side
-// stream's tail + the cross-stream signal latency, measured 7-13 us each, 12 per step), the side stream drops a mark after each
-// weight gradient and the main stream waits for the mark just before the NEXT write of that buffer - half a block to a full
-// block later, when the mark has normally long been reached.
-enum { S_FC2 = 0, S_FC1, S_PROJ, S_QKV, S_ADA };
+// Lagged joins.  The weight-gradient stream only READS the backward temporaries (dy, dy2, dhpre, dqkv); the main stream must not
+// overwrite one before its reader has finished.  Joining the streams at every such point stalls the main stream for the side
+// stream's tail plus the cross-stream signal latency (7-13 us each, 12 per step).  Instead the temporaries exist twice (consecutive
+// blocks alternate), the side stream drops a mark behind a block's last weight gradient, and the main stream waits for that mark
+// two blocks later, when it has long been reached: one wait packet per block in the main queue.
+enum { S_FC2 = 0, S_ADA, S_BLK0, S_BLK1 };
 static int side_mark(const v4h_plan& p, int which) {
   if (hipEventRecord(p.evS[which], p.side) != hipSuccess) { v4h_set_error("mark failed"); return V4H_ERR_HIP; }
   return V4H_OK;
@@ -231,7 +231,8 @@ struct WS {
   float** gtab;  // device table of the grouped adaLN weight-gradient contraction
   float *dsilu, *gxw, *gc0w, *glin, *glinb;
   float *dxA, *dxB, *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
-  char *dvp, *dy, *dy2, *dhpre, *du, *dof, *dqkv, *dmod_t, *dcond, *dh_small, *dh_small2, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
+  char *dy[2], *dy2[2], *dhpre[2], *dqkv[2];
+  char *dvp, *du, *dof, *dmod_t, *dcond, *dh_small, *dh_small2, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
   size_t total;
 };
 
@@ -334,12 +335,14 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
     if (p.mapper()) w.dxpre = take(BT * p.Pxpad * es);
-    w.dy = take(BT * D * es);
-    w.dy2 = take(BT * D * es);
-    w.dhpre = take(BT * M * es);
+    for (int k = 0; k < 2; ++k) {  // two sets, used alternately by consecutive blocks (lagged joins of the backward)
+      w.dy[k] = take(BT * D * es);
+      w.dy2[k] = take(BT * D * es);
+      w.dhpre[k] = take(BT * M * es);
+      w.dqkv[k] = take(BT * 3 * D * es);
+    }
     w.du = take(BT * D * es);
     w.dof = take(BT * D * es);
-    w.dqkv = take(BT * 3 * D * es);
     w.dmod_t = take((size_t)B * p.ldmod() * es);
     w.gtab = (float**)take(sizeof(PtrTable));
     w.dcond = take((size_t)B * D * es);
@@ -588,7 +591,8 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
   // (B, ldmod) table like the forward's.  Staged passes (gradient buckets reduced while later stages run) need each block's adaLN
   // gradients final at the end of its stage and keep the per-block launches, with per-block (B, 6 D) buffers in the same memory.
   const int ldm = p->ldmod();
-  const bool batch_ada = g_batch_adaln && stage_first == 0 && stage_last == depth + 1 && w.adaW != nullptr && 3 * depth + 1 <= V4H_GEMM_MAX_GROUPS && D % 8 == 0;
+  const bool whole_pass = stage_first == 0 && stage_last == depth + 1;
+  const bool batch_ada = g_batch_adaln && whole_pass && w.adaW != nullptr && 3 * depth + 1 <= V4H_GEMM_MAX_GROUPS && D % 8 == 0;
   const int ldd = batch_ada ? ldm : 6 * D, lddf = batch_ada ? ldm : 2 * D;
   auto dmod = [&](int i) { return w.dmod_base + (batch_ada ? (size_t)i * 6 * D : (size_t)i * B * 6 * D); };
   float* const dmodf = dmod(depth);
@@ -612,7 +616,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = p->ldmod();
       l.dx_out = dxbuf(0); l.dshift = dmodf; l.dscale = dmodf + D; l.ld_dmod = lddf;
-      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = dmod(depth - 1) + 5 * D; l.ld_dgate = ldd;
+      l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy[(depth - 1) & 1]; l.dgate = dmod(depth - 1) + 5 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       if (!batch_ada) RUN(adaln_backward(c, dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
@@ -624,52 +628,61 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       float* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
       const bool ov = g_overlap_wgrad;
       hipStream_t ws_ = ov ? p->side : c.s;  // stream of the weight-gradient contractions
-      // marks of the previous block exist only if that block ran in THIS call (every call ends with a full join)
-      const bool prev = ov && st > stage_first && st - 1 >= 1;
+      // The four temporaries a block's weight gradients read exist twice; block i uses set i & 1.
+      char *dy_i = w.dy[i & 1], *dy2_i = w.dy2[i & 1], *dh_i = w.dhpre[i & 1], *dq_i = w.dqkv[i & 1];
+      // The main stream may not write a set before the weight gradients of block i+2, its previous readers, are done: ONE wait per block
+      // (for the mark that block left behind its last weight gradient - two blocks old, long reached) instead of one per temporary.
+      // [Tried: a single fork per block, handing the side stream all four weight gradients at the block's end: 186.5 vs 189.2 steps/s.]
+      auto wg = [&](int k) -> int {
+        switch (k) {
+          case 0: return wgrad(c, dy_i, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_);
+          case 1: return wgrad(c, dh_i, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_);
+          case 2: return wgrad(c, dy2_i, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_);
+          default: return wgrad(c, dq_i, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_);
+        }
+      };
+      auto fork_wgrad = [&](int k) -> int {  // one weight gradient on the side stream as soon as its dY exists
+        if (ov) RUN(side_wait_main(*p, c.s));
+        return wg(k);
+      };
+      if (ov) RUN(main_wait_mark(*p, S_BLK0 + (i & 1), c.s));
       // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
-      if (ov) RUN(side_wait_main(*p, c.s));  // dy (and h) ready
-      RUN(wgrad(c, w.dy, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_));
+      RUN(fork_wgrad(0));  // dy (and h) ready
       if (ov) RUN(side_mark(*p, S_FC2));
-      if (prev) RUN(main_wait_mark(*p, S_FC1, c.s));  // dhpre is about to be overwritten: its reader of the previous block must be done
-      GemmArgs a = gargs(w.dy, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
-      a.e.out = w.dhpre; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
+      GemmArgs a = gargs(dy_i, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
+      a.e.out = dh_i; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
       RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
-      if (ov) RUN(side_wait_main(*p, c.s));  // dhpre ready
-      RUN(wgrad(c, w.dhpre, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_));
-      if (ov) RUN(side_mark(*p, S_FC1));
-      a = gargs(w.dhpre, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
+      RUN(fork_wgrad(1));  // dhpre ready
+      a = gargs(dh_i, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      if (prev) RUN(main_wait_mark(*p, S_PROJ, c.s));  // dy2 is about to be overwritten
       LnBwdArgs l;
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = p->ldmod();
       l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = dmod(i) + 3 * D; l.dscale = dmod(i) + 4 * D; l.ld_dmod = ldd;
-      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy2; l.dgate = dmod(i) + 2 * D; l.ld_dgate = ldd;
+      l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = dy2_i; l.dgate = dmod(i) + 2 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
-      if (ov) RUN(side_wait_main(*p, c.s));  // dy2 ready
-      RUN(wgrad(c, w.dy2, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_));
-      if (ov) RUN(side_mark(*p, S_PROJ));
-      a = gargs(w.dy2, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
+      RUN(fork_wgrad(2));  // dy2 ready
+      a = gargs(dy2_i, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
       a.e.out = w.dof; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      if (prev) RUN(main_wait_mark(*p, S_QKV, c.s));  // dqkv is about to be overwritten
-      RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, w.dqkv, B, T, p->H, p->DH, c.s));
-      if (ov) RUN(side_wait_main(*p, c.s));  // dqkv ready
-      RUN(wgrad(c, w.dqkv, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_));
-      if (ov) RUN(side_mark(*p, S_QKV));
-      a = gargs(w.dqkv, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
+      RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, dq_i, B, T, p->H, p->DH, c.s));
+      RUN(fork_wgrad(3));  // dqkv ready
+      if (ov) RUN(side_mark(*p, S_BLK0 + (i & 1)));
+      a = gargs(dq_i, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      if (ov) RUN(main_wait_mark(*p, S_FC2, c.s));  // dy (read by this block's fc2 weight gradient, first in the side queue) is about to be overwritten
+      // the LayerNorm backward below writes dy of block i-1 into the set block i+1 used: that block's fc2 weight gradient precedes this
+      // block's in the side queue, and this block's was issued a whole block ago
+      if (ov) RUN(main_wait_mark(*p, S_FC2, c.s));
       memset(&l, 0, sizeof(l));
       l.du = w.du; l.x = w.X[i]; l.mean = b.mean1; l.rstd = b.rstd1; l.scale = w.mod[i] + D; l.ld_mod = p->ldmod();
       l.dx_in = dx_mid; l.dshift = dmod(i); l.dscale = dmod(i) + D; l.ld_dmod = ldd;
       if (i > 0) {
         l.dx_out = dx_out;
-        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy; l.dgate = dmod(i - 1) + 5 * D; l.ld_dgate = ldd;
+        l.y = w.blk[i - 1].y2; l.gate = w.mod[i - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy[(i - 1) & 1]; l.dgate = dmod(i - 1) + 5 * D; l.ld_dgate = ldd;
       } else {
         l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
       }
