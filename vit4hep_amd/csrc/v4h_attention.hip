@@ -443,6 +443,169 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
   }
 }
 
+// ------------------------------------------------------------------------------------------------- backward, fused + persistent
+// Single-chunk case (T <= 160), bf16: one persistent workgroup per CU walks (batch, head) items and computes dQ, dK and dV of an item in two
+// phases that ping-pong two pairs of dense LDS images (AttnDense, global_load_lds):
+//   phase 1  dQ      streams K, V from LDS   (lane side: this wave's 16 query rows of Q and dO, from global memory)
+//            ... meanwhile the DMA brings this item's Q and dO into the other pair
+//   phase 2  dK, dV  streams Q, dO from LDS  (lane side: this wave's 16 key rows of K and V, read from the images before phase 1 ends)
+//            ... meanwhile the DMA brings the NEXT item's K and V
+// so apart from the first K, V of a workgroup no load is exposed, the scores' ingredients are fetched once per item instead of once per
+// kernel, and delta = rowsum(dO * O) and the log-sum-exp go from phase 1 to phase 2 through LDS instead of through HBM.
+template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                                                                   const T* __restrict__ dout, const float* __restrict__ lse,
+                                                                                                   T* __restrict__ dqkv, int Tn, int H, int nitems, float scale) {
+  using C = AttnCfg<T, DH>;
+  using DI = AttnDense<T, DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K | V | Q | dO | lse[KC] | delta[KC]]
+  char* iK = smem;
+  char* iV = smem + DI::BYTES;
+  char* iQ = smem + 2 * DI::BYTES;
+  char* iDO = smem + 3 * DI::BYTES;
+  const T *sK = reinterpret_cast<const T*>(iK), *sV = reinterpret_cast<const T*>(iV), *sQ = reinterpret_cast<const T*>(iQ), *sDO = reinterpret_cast<const T*>(iDO);
+  float* sLse = reinterpret_cast<float*>(smem + 4 * DI::BYTES);
+  float* sDelta = sLse + KC;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * DH, ld = 3 * D;
+  const int ntiles = (Tn + 15) / 16;
+  const bool active = wave < ntiles;
+  const int row = wave * 16 + c;  // this lane's lane-side row: a query in phase 1, a key in phase 2
+  auto kfrag = [&](const T* img, int jt, int s2) {  // regs-side fragment of streamed rows jt*16.. from a dense image, zero beyond head_dim
+    Frag<T> f = frag_kcontig(img, DH, jt * 16, 32 * s2, lane);
+    if (32 * s2 + 8 * g + 8 > DH) f = frag_zero<T>();
+    return f;
+  };
+  auto scores = [&](const T* img, int jt, const Frag<T>* x) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < C::NKF; ++s2) a = mma(kfrag(img, jt, s2), x[s2], a);
+    return a;
+  };
+  auto accumulate = [&](f32x4* out, f32x4 w0, f32x4 w1, const T* img, int ks) {
+    const Frag<T> wf = frag_from_acc(w0, w1, T());
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) out[dt] = mma(frag_kstrided2(img, DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, out[dt]);
+  };
+  for (int r = ntiles * 16 + tid; r < KC; r += 64 * NW) {  // rows no wave owns: never written again, read (and masked) by phase 2
+    sLse[r] = 0.f;
+    sDelta[r] = 0.f;
+  }
+  int it = blockIdx.x;
+  if (it < nitems) {
+    const T* base = qkv + (size_t)(it / H) * Tn * ld + (it % H) * DH;
+    DI::stage(iK, base + D, ld, Tn, wave, NW, lane);
+    DI::stage(iV, base + 2 * D, ld, Tn, wave, NW, lane);
+  }
+  for (; it < nitems; it += gridDim.x) {
+    const int b = it / H, h = it % H;
+    const T* base = qkv + (size_t)b * Tn * ld + h * DH;
+    const T* dobase = dout + (size_t)b * Tn * D + h * DH;
+    // ---- phase 1: dQ
+    Frag<T> xq[C::NKF], xdo[C::NKF];
+    load_row_frags<T, DH>(xq, base, ld, wave * 16, active ? Tn : 0, lane);
+    load_row_frags<T, DH>(xdo, dobase, D, wave * 16, active ? Tn : 0, lane);
+    float lse_q = 0.f, delta_q = 0.f;
+    {
+      Frag<T> xo[C::NKF];
+      load_row_frags<T, DH>(xo, o + (size_t)b * Tn * D + h * DH, D, wave * 16, active ? Tn : 0, lane);
+#pragma unroll
+      for (int s2 = 0; s2 < C::NKF; ++s2)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) delta_q += to_f32(xo[s2].v[jj]) * to_f32(xdo[s2].v[jj]);
+      delta_q += __shfl_xor(delta_q, 16, 64);
+      delta_q += __shfl_xor(delta_q, 32, 64);
+    }
+    if (active && row < Tn) lse_q = lse[((size_t)b * H + h) * Tn + row];
+    __syncthreads();  // (A) K and V of this item have landed; nobody reads the previous item's Q / dO images, lse or delta any more
+    DI::stage(iQ, base, ld, Tn, wave, NW, lane);
+    DI::stage(iDO, dobase, D, Tn, wave, NW, lane);
+    if (active && g == 0) {
+      sLse[row] = lse_q;      // rows >= Tn hold 0 (masked in phase 2)
+      sDelta[row] = row < Tn ? delta_q : 0.f;
+    }
+    if (active) {
+      f32x4 dq[C::NDT];
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::NJT / 2; ++ks) {  // two key tiles at a time: scores -> dS -> straight into dQ
+        f32x4 ds2[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int jt = 2 * ks + hh;
+          const f32x4 sc = scores(sK, jt, xq);
+          const f32x4 dp = scores(sV, jt, xdo);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = jt * 16 + 4 * g + r;
+            const float pr = (key < Tn && row < Tn) ? __expf(sc[r] * scale - lse_q) : 0.f;
+            ds2[hh][r] = pr * (dp[r] - delta_q) * scale;
+          }
+        }
+        accumulate(dq, ds2[0], ds2[1], sK, ks);
+      }
+      if (row < Tn) {
+        T* out = dqkv + ((size_t)b * Tn + row) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) store4(out + dt * 16 + 4 * g, dq[dt]);
+      }
+    }
+    // lane-side operands of phase 2: this wave's 16 key rows, from the K / V images (rows >= T are zero) before the next item's DMA overwrites them
+    Frag<T> xk[C::NKF], xv[C::NKF];
+#pragma unroll
+    for (int s2 = 0; s2 < C::NKF; ++s2) {
+      xk[s2] = kfrag(sK, wave, s2);
+      xv[s2] = kfrag(sV, wave, s2);
+    }
+    __syncthreads();  // (B) Q and dO have landed, lse / delta are complete; every wave holds its K / V fragments, the images are free
+    if (it + (int)gridDim.x < nitems) {
+      const int nx = it + gridDim.x;
+      const T* nbase = qkv + (size_t)(nx / H) * Tn * ld + (nx % H) * DH;
+      DI::stage(iK, nbase + D, ld, Tn, wave, NW, lane);
+      DI::stage(iV, nbase + 2 * D, ld, Tn, wave, NW, lane);
+    }
+    // ---- phase 2: dK, dV
+    if (active) {
+      f32x4 dk[C::NDT], dv[C::NDT];
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int ks = 0; ks < C::NJT / 2; ++ks) {  // two query tiles at a time: P^T, dS^T -> straight into dV, dK
+        f32x4 pt2[2], dst2[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int jt = 2 * ks + hh;
+          const f32x4 sc = scores(sQ, jt, xk);
+          const f32x4 dp = scores(sDO, jt, xv);
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(sLse + jt * 16 + 4 * g);
+          const f32x4 de = *reinterpret_cast<const f32x4*>(sDelta + jt * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = jt * 16 + 4 * g + r;
+            const float pr = (qq < Tn && row < Tn) ? __expf(sc[r] * scale - ls[r]) : 0.f;
+            pt2[hh][r] = pr;
+            dst2[hh][r] = pr * (dp[r] - de[r]) * scale;
+          }
+        }
+        accumulate(dv, pt2[0], pt2[1], sDO, ks);
+        accumulate(dk, dst2[0], dst2[1], sQ, ks);
+      }
+      if (row < Tn) {
+        T* out = dqkv + ((size_t)b * Tn + row) * ld + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+          store4(out + D + dt * 16 + 4 * g, dk[dt]);
+          store4(out + 2 * D + dt * 16 + 4 * g, dv[dt]);
+        }
+      }
+    }
+  }
+}
+
 template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -515,6 +678,20 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
                                      hipStream_t s) {
   V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (only 80)", DH);
   const int ntiles = (Tn + 15) / 16;
+  if constexpr (sizeof(T) == 2) {
+    static const bool fused = !(getenv("V4H_ATTN_BWD_FUSED") && getenv("V4H_ATTN_BWD_FUSED")[0] == '0');
+    if (fused && Tn <= KC && ntiles <= 9) {  // single chunk: dQ, dK, dV of an item in one persistent, double-buffered kernel
+      constexpr int NW = 9;
+      const size_t lds = 4 * (size_t)AttnDense<T, 80>::BYTES + 2 * KC * sizeof(float);
+      int rc = set_lds(attn_bwd_fused_kernel<T, 80, NW>, lds, "attn_bwd_fused");
+      if (rc) return rc;
+      const int nitems = B * H;
+      hipLaunchKernelGGL((attn_bwd_fused_kernel<T, 80, NW>), dim3(nitems < 256 ? nitems : 256), dim3(64 * NW), lds, s, (const T*)qkv, (const T*)o, (const T*)dout, lse,
+                         (T*)dqkv, Tn, H, nitems, 1.0f / sqrtf((float)DH));
+      V4H_CHECK_LAUNCH("attn_bwd_fused");
+      return V4H_OK;
+    }
+  }
   if (sizeof(T) == 4 || ntiles <= 4) return attn_bwd_launch<T, 4>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
   if (ntiles % 9 == 0) return attn_bwd_launch<T, 9>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
   return attn_bwd_launch<T, 8>(qkv, o, dout, lse, delta, dqkv, B, Tn, H, DH, s);
