@@ -32,7 +32,7 @@ if REPO not in sys.path:
 
 # HBM bytes per update step from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_step.sh; FETCH_SIZE doubled
 # per MI355X_MICROARCH.md because the reads are 16-byte-per-lane streams, WRITE_SIZE as is): profiles/r01_step_hbm_traffic.txt
-MEASURED_HBM_BYTES_PER_STEP = {("ds2", "bf16"): 2 * 5.194e9 + 5.189e9}
+MEASURED_HBM_BYTES_PER_STEP = {("ds2", "bf16"): 2 * 4.900e9 + 5.170e9}
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector rate
 
