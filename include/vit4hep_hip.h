@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 3
+#define V4H_ABI_VERSION 4
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -89,6 +89,14 @@ int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_pa
 int32_t v4h_vit_backward(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout, void* d_workspace,
                          size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream, const int32_t* d_patch_map, const float* d_pos);
 int32_t v4h_vit_num_backward_stages(const v4h_plan* plan);
+/* The whole backward pass (stages 0 .. depth+1) as ONE call that still lets the caller overlap the gradient all-reduce: stage_events is a
+ * host array of v4h_vit_num_backward_stages() hipEvent_t handles; event s is recorded - on whichever internal stream completes them - as
+ * soon as the gradient tensors of stage s are final.  A communication stream that waits for event s may reduce that stage's gradients
+ * while later stages still run (what DDP's bucket hooks do for the reference, experiments/base_experiment.py:161-167), and the two
+ * internal streams are joined once per pass instead of once per stage.  `stream` itself is ordered after the complete pass on return. */
+int32_t v4h_vit_backward_events(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout,
+                                void* d_workspace, size_t workspace_bytes, void* stream, const int32_t* d_patch_map, const float* d_pos,
+                                void* const* stage_events);
 
 /* ---- energy-model velocity field: ParallelTransformer.forward (nn/cfm/transformer_cfm.py:12-119), forward only --------------
  * The network the reference samples the layer-energy ratios from before the shape model runs

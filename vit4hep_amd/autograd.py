@@ -75,6 +75,26 @@ def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=Non
     )
 
 
+def run_backward_events(net, params, grads, dout_vox, ws, stage_events):
+    """The whole backward pass as one library call; ``stage_events[s]`` (torch.cuda.Event, already created) is recorded as soon as the
+    gradients of stage s are final (include/vit4hep_hip.h: v4h_vit_backward_events)."""
+    plan = net._get_plan()
+    if len(stage_events) != plan.num_stages:
+        raise RuntimeError(f"need {plan.num_stages} stage events, got {len(stage_events)}")
+    handles = (_lib.C.c_void_p * len(stage_events))()
+    for i, ev in enumerate(stage_events):
+        h = ev.cuda_event
+        if not h:
+            raise RuntimeError("stage event not created yet: record it once before the first use")
+        handles[i] = h
+    pmap, pos = net.device_tables(ws.device)
+    _lib.check(
+        _lib.load().v4h_vit_backward_events(plan.handle, dout_vox.shape[0], _lib.pointer_table(params), _lib.pointer_table(grads), _lib.ptr(dout_vox), _lib.ptr(ws),
+                                            ws.numel(), _lib.stream_ptr(ws.device), _lib.ptr(pmap), _lib.ptr(pos), handles),
+        "v4h_vit_backward_events",
+    )
+
+
 def _prep_inputs(net, x, t, c):
     x = _lib.require_cuda(x, "x")
     c = _lib.require_cuda(c, "c")

@@ -569,8 +569,10 @@ static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int 
   return V4H_OK;
 }
 
-extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
-                                    int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos) {
+// stage_events (optional, whole passes only): hipEvent_t per stage, recorded - on whichever stream finishes the stage's gradients - as soon as
+// the gradient tensors of that stage are final, so the caller can start reducing them without the streams being joined at every stage.
+static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
+                         int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos, void* const* stage_events) {
   RUN(check_common(p, B, params, ws, ws_bytes, true, "vit_backward"));
   RUN(check_geom(p, pmap, pos, "vit_backward"));
   V4H_CHECK_ARG(grads != nullptr, "vit_backward: null gradient table");
@@ -592,7 +594,12 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
   // gradients final at the end of its stage and keep the per-block launches, with per-block (B, 6 D) buffers in the same memory.
   const int ldm = p->ldmod();
   const bool whole_pass = stage_first == 0 && stage_last == depth + 1;
-  const bool batch_ada = g_batch_adaln && whole_pass && w.adaW != nullptr && 3 * depth + 1 <= V4H_GEMM_MAX_GROUPS && D % 8 == 0;
+  auto stage_done = [&](int st, hipStream_t on) -> int {
+    if (stage_events && hipEventRecord((hipEvent_t)stage_events[st], on) != hipSuccess) { v4h_set_error("vit_backward: cannot record the event of stage %d", st); return V4H_ERR_HIP; }
+    return V4H_OK;
+  };
+  // (with stage events the caller reduces each block's gradients while the pass runs: every block's adaLN gradients must be final with its stage)
+  const bool batch_ada = g_batch_adaln && whole_pass && !stage_events && w.adaW != nullptr && 3 * depth + 1 <= V4H_GEMM_MAX_GROUPS && D % 8 == 0;
   const int ldd = batch_ada ? ldm : 6 * D, lddf = batch_ada ? ldm : 2 * D;
   auto dmod = [&](int i) { return w.dmod_base + (batch_ada ? (size_t)i * 6 * D : (size_t)i * B * 6 * D); };
   float* const dmodf = dmod(depth);
@@ -620,6 +627,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       if (!batch_ada) RUN(adaln_backward(c, dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
+      RUN(stage_done(0, ov0 ? p->side : c.s));  // final-layer gradients: all on the weight-gradient stream
     } else if (st <= depth) {
       const int j = st - 1, i = depth - 1 - j;
       const BlockWS& b = w.blk[i];
@@ -690,6 +698,7 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
       l.B = B; l.T = T; l.D = D;
       RUN(ln_modulate_bwd(m, l, c.s));
       if (!batch_ada) RUN(adaln_backward(c, dmod(i), 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
+      RUN(stage_done(st, ws_));  // the block's weight gradients (and, unbatched, its adaLN gradients) are the last thing in the side queue
     } else {
       // --- embedders (nn/vit.py:76-82,193-199) ---
       // Three independent chains of small launches: x_embedder (+ mapper, positional table), c_embedder, t_embedder.  The first and the
@@ -756,7 +765,19 @@ extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* co
   // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
   // kernel is left reading a temporary the next call may overwrite.
   if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));
+  if (stage_last == depth + 1) RUN(stage_done(depth + 1, c.s));
   return V4H_OK;
+}
+
+extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
+                                    int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos) {
+  return backward_impl(p, B, params, grads, dout, ws, ws_bytes, stage_first, stage_last, stream, pmap, pos, nullptr);
+}
+extern "C" int32_t v4h_vit_backward_events(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws,
+                                           size_t ws_bytes, void* stream, const int32_t* pmap, const float* pos, void* const* stage_events) {
+  V4H_CHECK_ARG(p != nullptr && stage_events != nullptr, "vit_backward_events: null plan or event table");
+  for (int st = 0; st < p->depth + 2; ++st) V4H_CHECK_ARG(stage_events[st] != nullptr, "vit_backward_events: null event for stage %d", st);
+  return backward_impl(p, B, params, grads, dout, ws, ws_bytes, 0, p->depth + 1, stream, pmap, pos, stage_events);
 }
 
 // ------------------------------------------------------------------------------------------------ CFM step pieces

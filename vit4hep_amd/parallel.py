@@ -3,8 +3,9 @@
 
 The gradient lives in ONE flat f32 buffer laid out in state_dict() order, so each backward stage of the HIP runtime
 (final layer, block depth-1 ... block 0, embedders) finishes a CONTIGUOUS slice.  ``BucketReducer`` all-reduces each
-slice as soon as its stage has been enqueued, on a side stream, so the collective of stage s overlaps the kernels of
-stage s+1.  Buckets are therefore 0.1 / 17.3 x depth / 2.0 MB (f32): few, large messages as xGMI's point-to-point rings like.
+slice as soon as its stage's gradients are final, on a communication stream, so the collective of stage s overlaps the kernels of
+the later stages.  On the GPU the whole backward is ONE library call that records an event per stage (v4h_vit_backward_events); the
+collectives are enqueued behind those events.  (CPU / gloo: one call per stage, reduce after each.)  Buckets are therefore 0.1 / 17.3 x depth / 2.0 MB (f32): few, large messages as xGMI's point-to-point rings like.
 The 1/world factor of DDP's gradient averaging is folded into the loss gradient, so the collective is a plain SUM.
 Works on CPU tensors with the gloo backend too (tests/test_dp_gloo.py).
 """
@@ -51,6 +52,21 @@ class BucketReducer:
                 self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def make_stage_events(self, n: int):
+        """Events the HIP runtime records when a backward stage's gradients are final (v4h_vit_backward_events)."""
+        evs = [torch.cuda.Event() for _ in range(n)]
+        for ev in evs:  # torch creates the underlying hipEvent_t at the first record
+            ev.record(torch.cuda.current_stream(self.flat.device))
+        return evs
+
+    def reduce_slice_after(self, lo: int, hi: int, event):
+        """All-reduce flat[lo:hi] on the communication stream once ``event`` (recorded by the library inside the backward call) is reached."""
+        if not collectives_enabled() or hi <= lo:
+            return
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(event)
+            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Make the current stream (or the host, on CPU) wait for every outstanding bucket."""

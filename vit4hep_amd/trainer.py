@@ -2,7 +2,7 @@
 with configs/training/default.yaml) on flat HBM buffers, without autograd and without per-step host syncs.
 
   loss  = CFM._batch_loss                         (models/base_model.py:203-218)   -> HIP forward + fused MSE
-  grads = loss.backward()                         (:560)                           -> staged HIP backward
+  grads = loss.backward()                         (:560)                           -> HIP backward, one call (stage events for the buckets)
   DDP gradient averaging                          (:161-167)                       -> bucketed RCCL all-reduce, overlapped
   clip_grad_norm_(..., clip, error_if_nonfinite)  (:573-585)                       -> one norm kernel; clip folded into AdamW
   AdamW(lr, betas, eps, wd) + CosineAnnealingLR   (:592-597, :329-431)             -> one fused kernel over all parameters
@@ -14,12 +14,13 @@ Loss and gradient norm come back as 0-dim device tensors; call ``check_finite`` 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import _lib
-from .autograd import run_backward, run_forward
+from .autograd import run_backward, run_backward_events, run_forward
 from .parallel import BucketReducer, collectives_enabled, world
 
 
@@ -77,6 +78,7 @@ class CFMTrainer:
             self.stage_slices.append(bounds(blk0 + 10 * i, blk0 + 10 * (i + 1)))
         self.stage_slices.append(bounds(0, blk0))
         self.reducer = BucketReducer(self.flat_g, self.group)
+        self.stage_events = None
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
 
@@ -116,8 +118,16 @@ class CFMTrainer:
         if W > 1:  # DDP averages gradients: fold 1/world into the seed, then SUM
             _lib.check(lib.v4h_axpby(_lib.ptr(dv), _lib.ptr(dv), _lib.ptr(dv), 1.0 / W, 0.0, dv.numel(), s), "v4h_axpby")
         self.flat_g.zero_()
-        if collectives_enabled():
-            for st, (lo, hi) in enumerate(self.stage_slices):  # each call ends with a stream join: the stage's gradients are final
+        if collectives_enabled() and os.environ.get("V4H_STAGED_CALLS") != "1":
+            # one call; the library records an event when a stage's gradient slice is final and the bucket is reduced behind it
+            if self.stage_events is None:
+                self.stage_events = self.reducer.make_stage_events(len(self.stage_slices))
+            run_backward_events(self.net, self.p_views, self.g_views, dv, ws, self.stage_events)
+            for (lo, hi), ev in zip(self.stage_slices, self.stage_events):
+                self.reducer.reduce_slice_after(lo, hi, ev)
+            self.reducer.finish()
+        elif collectives_enabled():  # A/B hook: one call per stage, each ending with a join of the library's two streams
+            for st, (lo, hi) in enumerate(self.stage_slices):
                 run_backward(self.net, self.p_views, self.g_views, dv, ws, st, st)
                 self.reducer.reduce_slice(lo, hi)
             self.reducer.finish()
