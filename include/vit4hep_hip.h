@@ -42,6 +42,10 @@ typedef struct v4h_config {
                              the embedding mapper of fine-tuning (experiments/calochallenge/calochallenge_cfm/experiment_finetuning.py:80-91).
                              Its two tensors (weight (x_embed_in, patch_dim), bias) come LAST in the parameter tables; x_embedder.{weight,bias} at
                              indices 1, 2 are then those of the inner Linear, (hidden_dim, x_embed_in). */
+  int32_t c_embed_in;     /* 0, or: the c_embedder is Sequential(Linear(condition_dim -> c_embed_in), SiLU, <the backbone's c_embedder>), the
+                             condition-embedding mapper of fine-tuning (experiment_finetuning.py:106-119).  condition_dim is then the width of the
+                             conditions the caller passes, c_embed_in the input width of c_embedder.0 (indices 3, 4).  The mapper's two tensors
+                             (weight (c_embed_in, condition_dim), bias) come LAST in the parameter tables, after those of the x mapper if both exist. */
 } v4h_config;
 
 typedef struct v4h_plan v4h_plan; /* host-side object: derived sizes and workspace offsets, no device state */

@@ -333,7 +333,7 @@ def make_energy_case(name, cfg: E.EnergyConfig, B, seed, sample_specs):
     print(f"{name}: loss={loss.item():.6f} |v|={float(np.abs(out['velocity']).max()):.4f} nparams={int(out['nparams'])} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
-def make_mapper_case(name, back: O.ViTConfig, new: O.ViTConfig, B, seed):
+def make_mapper_case(name, back: O.ViTConfig, new: O.ViTConfig, B, seed, map_c=False):
     """Fine-tuning with an embedding mapper (experiments/calochallenge/calochallenge_cfm/experiment_finetuning.py:75-171, flags of
     configs/calochallenge/finetuning/calochallenge_ds2tods3_ft.yaml: map_x_embedding, reinitialize_pos_embedding, reinitialize_final_layer):
     the reference's own modules, surgery statements as in add_embedding_layers()."""
@@ -351,9 +351,11 @@ def make_mapper_case(name, back: O.ViTConfig, new: O.ViTConfig, B, seed):
     pos_z, pos_y, pos_x = net.create_meshgrid()
     net.pos_z, net.pos_y, net.pos_x = pos_z, pos_y, pos_x
     net.final_layer = FinalLayer(back.hidden_dim, new.P, 1)
+    if map_c:  # map_c_embedding as well (experiment_finetuning.py:106-119): conditions of the new dataset's width in front of the backbone's embedder
+        net.c_embedder = nn.Sequential(nn.Linear(new.condition_dim, back.condition_dim), nn.SiLU(), net.c_embedder)
     with torch.no_grad():
         for k, p_ in model.named_parameters():
-            if k.startswith("net.x_embedder.0.") or k.startswith("net.final_layer."):
+            if k.startswith("net.x_embedder.0.") or k.startswith("net.final_layer.") or (map_c and k.startswith("net.c_embedder.0.")):
                 p_.copy_(O.fill_tensor("ft/" + k[4:], tuple(p_.shape)))
     model.train()
     x, c, g = O.synthetic_batch(new, B, seed)
@@ -433,6 +435,12 @@ def main():
     _install_standins()
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])  # optional: names of the cases to (re)generate
+    if only:
+        g = globals()
+        for fn in ("make_case", "make_energy_case", "make_mapper_case", "make_transforms_case"):
+            g[fn] = (lambda f: lambda name, *a, **k: f(name, *a, **k) if name in only else None)(g[fn])
+        g["check_branches"] = lambda *a, **k: None
     check_branches(O.ds2(2))
     make_case("ds2_d2_b2", O.ds2(2), 2, 11, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)], 5)
     make_case("ds2_d6_b2", O.ds2(6), 2, 12, [("rk4_coarse", "rk4", 0.25)], 3)
@@ -447,6 +455,7 @@ def main():
     make_energy_case("energy_ds2_b5", E.EnergyConfig(), 5, 31, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)])
     # fine-tuning with an embedding mapper
     make_mapper_case("ft_mapper_d2_b2", O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2), 2, 51)
+    make_mapper_case("ft_xc_mapper_d2_b3", O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2, condition_dim=51), 3, 52, map_c=True)
     # pre-/post-processing chain
     make_transforms_case("transforms_ds2_b4", [(16, 9)] * 45, (1, 45, 16, 9), 4, 41, dict(mean=-1.7, std=2.9))
     make_transforms_case("transforms_ds1ph_b6", [(1, 8), (10, 16), (10, 19), (1, 5), (1, 5)], (368,), 6, 42, dict(mean=-0.8, std=3.3, factor=0.5, cut=1.0e-6))

@@ -357,7 +357,11 @@ def conditioning(p, t, c, cfg: ViTConfig):
     """t_embedder + c_embedder, summed   nn/vit.py:197-199, 361-365, 77-81"""
     te = timestep_embedding(t, cfg.freq_dim)
     te = linear(silu(linear(te, p, "t_embedder.mlp.0")), p, "t_embedder.mlp.2")
-    ce = linear(silu(linear(c, p, "c_embedder.0")), p, "c_embedder.2")
+    if "c_embedder.2.0.weight" in p:  # fine-tuning condition mapper: Sequential(Linear, SiLU, c_embedder)   experiment_finetuning.py:106-119
+        c = silu(linear(c, p, "c_embedder.0"))
+        ce = linear(silu(linear(c, p, "c_embedder.2.0")), p, "c_embedder.2.2")
+    else:
+        ce = linear(silu(linear(c, p, "c_embedder.0")), p, "c_embedder.2")
     return te + ce
 
 

@@ -138,11 +138,85 @@ def test_embedding_mapper_vs_reference_vectors(mode, golden):
         CFMTrainer(model)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_both_mappers_vs_reference_vectors(mode, golden):
+    """`map_x_embedding` + `map_c_embedding` (experiment_finetuning.py:79-119): c_embedder becomes Sequential(Linear(51 -> 46), SiLU, c_embedder);
+    golden vectors from the reference's own modules after the same surgery."""
+    from vit4hep_amd import CaloChallengeCFM
+    from vit4hep_amd.nn.vit import FinalLayer
+
+    g = golden("ft_xc_mapper_d2_b3")
+    back, new = O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2, condition_dim=51)
+    net = U.build_net(back, mode)
+    model = CaloChallengeCFM(net, list(new.patch_shape), in_channels=1, odeint_kwargs={"method": "rk4", "options": {"step_size": 0.5}}, shape=list(new.shape))
+    sd = model.state_dict()
+    for k, v in O.golden_fill(back).items():
+        sd["net." + k] = v.clone()
+    model.load_state_dict(sd)
+    model.device, model.dtype = torch.device(U.DEV), torch.float32
+    model = model.to(U.DEV)
+    net = model.net
+    net.x_embedder = nn.Sequential(nn.Linear(new.P, back.P), nn.SiLU(), net.x_embedder).to(U.DEV, torch.float32)
+    net.c_embedder = nn.Sequential(nn.Linear(new.condition_dim, back.condition_dim), nn.SiLU(), net.c_embedder).to(U.DEV, torch.float32)
+    net.num_patches = [list(new.num_patches)]
+    pos_z, pos_y, pos_x = net.create_meshgrid()
+    net.pos_z, net.pos_y, net.pos_x = pos_z.to(U.DEV), pos_y.to(U.DEV), pos_x.to(U.DEV)
+    net.final_layer = FinalLayer(back.hidden_dim, new.P, 1).to(U.DEV, torch.float32)
+    with torch.no_grad():
+        for k, p_ in model.named_parameters():
+            if k.startswith("net.x_embedder.0.") or k.startswith("net.c_embedder.0.") or k.startswith("net.final_layer."):
+                p_.copy_(O.fill_tensor("ft/" + k[4:], tuple(p_.shape)).to(U.DEV))
+    assert net.condition_dim == 51 and net.c_embed_in() == 46 and net.patch_dim == 24 and net.x_embed_in() == 48
+    x, c, t, x0 = (torch.from_numpy(g[k]).to(U.DEV) for k in ("x", "c", "t", "x0"))
+    loss = model._loss_from_noise(x, c, t, x0)
+    loss.backward()
+    tol = 1e-4 if mode == "f32" else 3e-2
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < tol
+    with torch.no_grad():
+        v = model.forward((1 - t) * x0 + t * x, t.view(-1, 1), c)
+    assert U.rel_err(v, torch.from_numpy(g["velocity"])) < tol
+    grads = U.named_grads(model)
+    names = [str(n) for n in g["names"]]
+    assert names == [k[4:] for k, _ in model.named_parameters()]
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    assert float(np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max()) < (3e-4 if mode == "f32" else 6e-2)
+    for k in names:
+        got = grads[k].flatten().double().cpu().numpy()[g["gidx/" + k]]
+        scale = max(float(np.abs(g["gval/" + k]).max()), 1e-2 * float(g["grad_norms"][names.index(k)]), 1e-12)
+        assert np.abs(got - g["gval/" + k]).max() / scale < (2e-3 if mode == "f32" else 0.25), k
+    with torch.inference_mode():
+        s = model.sample_batch(c)
+    assert s.shape == (3, 1, 45, 16, 9) and torch.isfinite(s).all()
+
+
+def test_condition_mapper_alone_vs_oracle():
+    """`map_c_embedding` without the x mapper, f32: forward and every gradient against the CPU oracle."""
+    back = O.ds2(1)
+    model = U.build_models(back, "f32", O.golden_fill(back))
+    net = model.net
+    net.c_embedder = nn.Sequential(nn.Linear(50, 46), nn.SiLU(), net.c_embedder).to(U.DEV)
+    with torch.no_grad():
+        for k, p_ in net.named_parameters():
+            if k.startswith("c_embedder.0."):
+                p_.copy_(O.fill_tensor("ft/" + k, tuple(p_.shape)).to(U.DEV))
+    new = O.ViTConfig(depth=1, condition_dim=50)
+    x, c, gen = O.synthetic_batch(new, 3, 4)
+    t, x0 = O.synthetic_noise(new, 3, gen)
+    p = {k: v.detach().cpu() for k, v in net.named_parameters()}
+    ref_loss, ref_v, ref_grads = O.loss_and_grads(p, x, c, t, x0, new)
+    loss = model._loss_from_noise(x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) / ref_loss.item() < 1e-4
+    grads = U.named_grads(model)
+    for k, ref in ref_grads.items():
+        assert U.rel_err(grads[k], ref) < 2e-3 or float(ref.abs().max()) < 1e-7, k
+
+
 def test_unsupported_surgery_is_refused_loudly():
     back = O.ds2(1)
     model = U.build_models(back, "f32", O.golden_fill(back))
     net = model.net
-    net.c_embedder = nn.Sequential(nn.Linear(50, 46), nn.SiLU(), net.c_embedder).to(U.DEV)  # map_c_embedding: used by no shipped config
+    net.c_embedder = nn.Sequential(nn.Linear(50, 46), nn.ReLU(), net.c_embedder).to(U.DEV)  # not the mapper of experiment_finetuning.py:106-119
     x, c, g = O.synthetic_batch(back, 2, 1)
-    with pytest.raises(NotImplementedError, match="map_c_embedding"):
+    with pytest.raises(NotImplementedError, match="c_embedder must be"):
         model.forward(x.to(U.DEV), torch.rand(2, 1, device=U.DEV), torch.zeros(2, 50, device=U.DEV))

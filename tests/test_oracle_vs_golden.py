@@ -132,3 +132,27 @@ def test_embedding_mapper_oracle_vs_reference(golden):
     names = [str(n) for n in g["names"]]
     norms = np.array([float(grads[k].double().norm()) for k in names])
     assert np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max() < 5e-5
+
+
+def test_both_mappers_oracle_vs_reference(golden):
+    """`map_x_embedding` and `map_c_embedding` together (experiment_finetuning.py:79-119): conditions of width 51 in front of the backbone's
+    46-wide c_embedder, patches of width 24 in front of its 48-wide x_embedder."""
+    g = golden("ft_xc_mapper_d2_b3")
+    back, new = O.ds2(2), O.ViTConfig(shape=(45, 16, 9), patch_shape=(3, 8, 1), depth=2, condition_dim=51)
+    p = dict(O.golden_fill(back))
+    p["x_embedder.2.weight"], p["x_embedder.2.bias"] = p.pop("x_embedder.weight"), p.pop("x_embedder.bias")
+    for a, b in (("c_embedder.0.weight", "c_embedder.2.0.weight"), ("c_embedder.0.bias", "c_embedder.2.0.bias"),
+                 ("c_embedder.2.weight", "c_embedder.2.2.weight"), ("c_embedder.2.bias", "c_embedder.2.2.bias")):
+        p[b] = p.pop(a)
+    for k, shp in (("x_embedder.0.weight", (48, 24)), ("x_embedder.0.bias", (48,)), ("c_embedder.0.weight", (46, 51)), ("c_embedder.0.bias", (46,)),
+                   ("final_layer.linear.weight", (24, 480)), ("final_layer.linear.bias", (24,)),
+                   ("final_layer.adaLN_modulation.1.weight", (960, 480)), ("final_layer.adaLN_modulation.1.bias", (960,))):
+        p[k] = O.fill_tensor("ft/" + k, shp)
+    loss, v, grads = O.loss_and_grads(p, *(torch.from_numpy(g[k]) for k in ("x", "c", "t", "x0")), new)
+    assert g["c"].shape == (3, 51)
+    assert rel(v.numpy(), g["velocity"]) < RTOL and abs(float(loss) - float(g["loss"])) / float(g["loss"]) < RTOL
+    names = [str(n) for n in g["names"]]
+    assert "c_embedder.0.weight" in names and "c_embedder.2.2.bias" in names
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    assert np.abs(norms - g["grad_norms"]).max() / g["grad_norms"].max() < 5e-5
+

@@ -34,6 +34,7 @@ class V4HConfig(C.Structure):
         ("freq_dim", C.c_int32),
         ("mode", C.c_int32),
         ("x_embed_in", C.c_int32),
+        ("c_embed_in", C.c_int32),
     ]
 
 
@@ -175,7 +176,7 @@ class Plan:
     ignored); forward / backward calls then need the index map and position table (include/vit4hep_hip.h)."""
 
     def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1, mapped=None,
-                 x_embed_in=0):
+                 x_embed_in=0, c_embed_in=0):
         lib = load()
         cfg = V4HConfig()
         cfg.shape[:] = [int(v) for v in (shape if mapped is None else (0, 0, 0))]
@@ -189,6 +190,7 @@ class Plan:
         cfg.freq_dim = int(freq_dim)
         cfg.mode = MODES[mode] if isinstance(mode, str) else int(mode)
         cfg.x_embed_in = int(x_embed_in)
+        cfg.c_embed_in = int(c_embed_in)
         self.mode = cfg.mode
         self.cfg = cfg
         h = C.c_void_p()

@@ -32,12 +32,16 @@ enum {  // parameter indices in state_dict() order (nn/vit.py:76-132)
 struct v4h_plan {
   v4h_config cfg;
   Mode mode;
-  int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;
+  int T, P, Ppad, D, H, DH, M, Kc, Kcpad, F, depth;  // Kc: input width of c_embedder.0 (= condition_dim without a condition mapper)
+  int Kcx, Kcxpad;  // width of the conditions the caller passes: Kc, or condition_dim in front of a condition-embedding mapper
   int Px, Pxpad;  // input width of the x_embedder Linear: P, or x_embed_in behind an embedding mapper
   bool mapper() const { return cfg.x_embed_in > 0; }
   int ldmod() const { return 6 * D * depth + 2 * D; }  // row stride of the modulation table: [block 0: 6 D | ... | block depth-1: 6 D | final layer: 2 D]
-  int xmw() const { return nparams() - 2; }  // mapper weight / bias: the last two tensors
-  int xmb() const { return nparams() - 1; }
+  bool cmapper() const { return cfg.c_embed_in > 0; }
+  int cmw() const { return nparams() - 2; }  // condition mapper weight / bias: the last two tensors
+  int cmb() const { return nparams() - 1; }
+  int xmw() const { return nparams() - 2 - (cmapper() ? 2 : 0); }  // x mapper weight / bias: before them
+  int xmb() const { return nparams() - 1 - (cmapper() ? 2 : 0); }
   PatchGeom pg;
   bool mapped = false;  // general geometry: gather / scatter through a caller-provided index map, positions from a caller-provided table
   long V = 0;           // voxels per sample
@@ -162,7 +166,10 @@ static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int pa
   p->H = c->num_heads;
   p->DH = p->D / p->H;
   p->M = c->mlp_hidden;
-  p->Kc = c->condition_dim;
+  V4H_CHECK_ARG(c->c_embed_in >= 0, "plan_create: c_embed_in %d", c->c_embed_in);
+  p->Kcx = c->condition_dim;
+  p->Kcxpad = round_up(p->Kcx, 32);
+  p->Kc = c->c_embed_in > 0 ? c->c_embed_in : c->condition_dim;
   p->Kcpad = round_up(p->Kc, 32);
   p->F = c->freq_dim;
   p->depth = c->depth;
@@ -179,6 +186,7 @@ static int plan_create_impl(const v4h_config* c, bool mapped, int tokens, int pa
   }
   add(p->P, D); add(p->P, 0); add(2 * D, D); add(2 * D, 0);
   if (p->mapper()) { add(p->Px, p->P); add(p->Px, 0); }
+  if (p->cmapper()) { add(p->Kc, p->Kcx); add(p->Kc, 0); }
   *out = p;
   return V4H_OK;
 }
@@ -227,6 +235,8 @@ struct WS {
   std::vector<BlockWS> blk;
   // backward
   char* zero_begin; size_t zero_bytes;
+  char *cin, *cmb_pad, *dcpre;  // condition mapper: its input operand, padded bias, d pre-activation
+  float *cpre, *gcmw, *gcmb;
   float* dmod_base;
   float** gtab;  // device table of the grouped adaLN weight-gradient contraction
   float *dsilu, *gxw, *gc0w, *glin, *glinb;
@@ -268,6 +278,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     if (i == P_XW) { cp = p.Pxpad; padded = true; }
     if (p.mapper() && i == p.xmw()) { rp = p.Pxpad; cp = p.Ppad; padded = true; }
     if (i == P_C0W) { cp = p.Kcpad; padded = true; }
+    if (p.cmapper() && i == p.cmw()) { rp = p.Kcpad; cp = p.Kcxpad; padded = true; }
     if (i == p.fin(F_LINW)) { rp = p.Ppad; padded = true; }
     if (p.mode == MODE_BF16 || padded) w.wop[i] = take((size_t)rp * cp * es);
   }
@@ -284,6 +295,12 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   w.ht_pre = (float*)take((size_t)B * D * 4);
   w.ht = take((size_t)B * D * es);
   w.cpad = take((size_t)B * p.Kcpad * es);
+  w.cin = nullptr; w.cpre = nullptr; w.cmb_pad = nullptr;
+  if (p.cmapper()) {
+    w.cin = take((size_t)B * p.Kcxpad * es);           // the caller's conditions (mapper input)
+    w.cpre = (float*)take((size_t)B * p.Kcpad * 4);    // mapper pre-activation (for silu')
+    w.cmb_pad = take((size_t)p.Kcpad * 4);             // mapper bias, zero-padded
+  }
   w.hc_pre = (float*)take((size_t)B * D * 4);
   w.hc = take((size_t)B * D * es);
   w.cond = (float*)take((size_t)B * D * 4);
@@ -325,6 +342,11 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
       w.gxmb = (float*)take((size_t)p.Pxpad * 4);
     }
     w.gc0w = (float*)take((size_t)D * p.Kcpad * 4);
+    w.gcmw = nullptr; w.gcmb = nullptr;
+    if (p.cmapper()) {
+      w.gcmw = (float*)take((size_t)p.Kcpad * p.Kcxpad * 4);
+      w.gcmb = (float*)take((size_t)p.Kcpad * 4);
+    }
     w.glin = (float*)take((size_t)p.Ppad * D * 4);
     w.glinb = (float*)take((size_t)p.Ppad * 4);
     w.zero_bytes = off - z0;
@@ -335,6 +357,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
     if (p.mapper()) w.dxpre = take(BT * p.Pxpad * es);
+    w.dcpre = p.cmapper() ? take((size_t)B * p.Kcpad * es) : nullptr;
     for (int k = 0; k < 2; ++k) {  // two sets, used alternately by consecutive blocks (lagged joins of the backward)
       w.dy[k] = take(BT * D * es);
       w.dy2[k] = take(BT * D * es);
@@ -448,6 +471,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       if (i == P_XW) cp = p->Pxpad;
       if (p->mapper() && i == p->xmw()) { rp = p->Pxpad; cp = p->Ppad; }
       if (i == P_C0W) cp = p->Kcpad;
+      if (p->cmapper() && i == p->cmw()) { rp = p->Kcpad; cp = p->Kcxpad; }
       if (i == p->fin(F_LINW)) rp = p->Ppad;
       items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
     }
@@ -458,7 +482,9 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       items.push_back(CastPadItem{c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB)), w.adaB + (size_t)i * 6 * D, 1, J, 1, J, 1});
     }
     if (!reuse && p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
-    items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
+    if (!reuse && p->cmapper()) items.push_back(CastPadItem{c.pf(p->cmb()), w.cmb_pad, 1, p->Kc, 1, p->Kcpad, 1});
+    if (p->cmapper()) items.push_back(CastPadItem{cnd, w.cin, B, p->Kcx, B, p->Kcxpad, 0});
+    else items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
     RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
   // The token path (to_patches, positional table, x_embedder) and the conditioning path (t/c embedders, adaLN table) are
@@ -493,6 +519,11 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
     a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B);
     RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
+    if (p->cmapper()) {  // fine-tuning condition mapper: c' = silu(c Wm^T + bm)   (experiment_finetuning.py:106-119)
+      a = gargs(w.cin, p->Kcxpad, c.W(p->cmw()), p->Kcxpad, B, p->Kcpad, p->Kcxpad);
+      a.e.out = w.cpad; a.e.ldo = p->Kcpad; a.e.out2 = training ? w.cpre : nullptr; a.e.ldo2 = p->Kcpad; a.e.bias = (const float*)w.cmb_pad;
+      RUN(gemm_fwd(m, EPI_SILU, a, cs));
+    }
     a = gargs(w.cpad, p->Kcpad, c.W(P_C0W), p->Kcpad, B, D, p->Kcpad);
     a.e.out = w.hc; a.e.ldo = D; a.e.out2 = w.hc_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_C0B);
     RUN(gemm_fwd(m, EPI_SILU, a, cs));
@@ -758,6 +789,14 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
       RUN(wgrad(c, w.dh_small, D, D, w.cpad, p->Kcpad, p->Kcpad, B, w.gc0w, p->Kcpad, (float*)grads[P_C0B]));
       RUN(unpad_f32(w.gc0w, p->Kcpad, (float*)grads[P_C0W], D, p->Kc, c.s));
+      if (p->cmapper()) {  // d pre = (d h . W_c0) * silu'(pre) ; d Wm = d pre^T c ; d bm = column sums
+        a = gargs(w.dh_small, D, c.W(P_C0W), p->Kcpad, B, p->Kcpad, D);
+        a.e.out = w.dcpre; a.e.ldo = p->Kcpad; a.e.auxf = w.cpre; a.e.ld_auxf = p->Kcpad;
+        RUN(gemm_dgrad(m, EPI_DSILU, a, c.s));
+        RUN(wgrad(c, w.dcpre, p->Kcpad, p->Kcpad, w.cin, p->Kcxpad, p->Kcxpad, B, w.gcmw, p->Kcxpad, w.gcmb));
+        RUN(unpad_f32(w.gcmw, p->Kcxpad, (float*)grads[p->cmw()], p->Kc, p->Kcx, c.s));
+        RUN(unpad_f32(w.gcmb, 1, (float*)grads[p->cmb()], p->Kc, 1, c.s));
+      }
       if (pos) RUN(pos_embed_bwd_pos(m, w.dx0_t, c.pf(P_FREQS), pos, (float*)grads[P_FREQS], w.G, B, T, D, c.s));
       else RUN(pos_embed_bwd(m, w.dx0_t, c.pf(P_FREQS), (float*)grads[P_FREQS], w.G, B, p->pg, D, c.s));
     }

@@ -111,6 +111,20 @@ class ViT(nn.Module):
     def _is_mapper(xe):
         return isinstance(xe, nn.Sequential) and len(xe) == 3 and isinstance(xe[0], nn.Linear) and isinstance(xe[1], nn.SiLU) and isinstance(xe[2], nn.Linear)
 
+    @staticmethod
+    def _is_c_embedder(ce):
+        return isinstance(ce, nn.Sequential) and len(ce) == 3 and isinstance(ce[0], nn.Linear) and isinstance(ce[1], nn.SiLU) and isinstance(ce[2], nn.Linear)
+
+    @classmethod
+    def _is_c_mapper(cls, ce):
+        """Sequential(mapper Linear, SiLU, <the backbone's c_embedder>): fine-tuning's `map_c_embedding` (experiment_finetuning.py:106-119)."""
+        return isinstance(ce, nn.Sequential) and len(ce) == 3 and isinstance(ce[0], nn.Linear) and isinstance(ce[1], nn.SiLU) and cls._is_c_embedder(ce[2])
+
+    def c_embed_in(self):
+        """Input width of the inner c_embedder behind a fine-tuning condition mapper, else 0."""
+        ce = self._modules.get("c_embedder")
+        return int(ce[2][0].weight.shape[1]) if self._is_c_mapper(ce) else 0
+
     def x_embed_in(self):
         """Input width of the inner x_embedder Linear behind a fine-tuning embedding mapper, else 0."""
         xe = self._modules.get("x_embedder")
@@ -281,8 +295,11 @@ class ViT(nn.Module):
         if self._is_mapper(xe) and int(xe[0].weight.shape[0]) != int(xe[2].weight.shape[1]):
             raise ValueError("embedding mapper: output width of the mapper differs from the input width of the x_embedder")
         ce = self._modules.get("c_embedder")
-        if not (isinstance(ce, nn.Sequential) and len(ce) == 3 and isinstance(ce[0], nn.Linear) and isinstance(ce[2], nn.Linear)):
-            raise NotImplementedError("vit4hep_amd: c_embedder must be Sequential(Linear, SiLU, Linear) (fine-tuning `map_c_embedding` is not implemented)")
+        if not (self._is_c_embedder(ce) or self._is_c_mapper(ce)):
+            raise NotImplementedError("vit4hep_amd: c_embedder must be Sequential(Linear, SiLU, Linear) or the fine-tuning mapper "
+                                      "Sequential(Linear, SiLU, Sequential(Linear, SiLU, Linear)) (experiment_finetuning.py:106-119)")
+        if self._is_c_mapper(ce) and int(ce[0].weight.shape[0]) != int(ce[2][0].weight.shape[1]):
+            raise ValueError("condition mapper: output width of the mapper differs from the input width of the c_embedder")
         if not isinstance(getattr(self.final_layer, "linear", None), nn.Linear):
             raise NotImplementedError("vit4hep_amd: final_layer must be a FinalLayer")
 
@@ -291,7 +308,7 @@ class ViT(nn.Module):
         g = self.geometry()
         T, P = self.num_tokens, int(self.patch_dim)
         key = (T, P, int(self.condition_dim), int(self.final_layer.linear.weight.shape[0]), g[0], tuple(g[1]) if g[0] == "grid" else g[2], id(self._patch_map),
-               self.x_embed_in())
+               self.x_embed_in(), self.c_embed_in())
         if self._plan is not None and getattr(self, "_plan_key", None) != key:  # embedders / head / position buffers were re-shaped
             self._plan, self._infer_ws, self._dev_tables, self._infer_sig = None, {}, None, None
         if self._plan is None:
@@ -306,7 +323,7 @@ class ViT(nn.Module):
             shape, patch_shape, mapped = (g[1], g[2], None) if g[0] == "grid" else (None, None, (self.num_tokens, int(self.patch_dim), g[2]))
             self._plan = _lib.Plan(shape, patch_shape, self.condition_dim, self.hidden_dim, self.depth, self.num_heads,
                                    int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped,
-                                   x_embed_in=self.x_embed_in())
+                                   x_embed_in=self.x_embed_in(), c_embed_in=self.c_embed_in())
             got = [tuple(p.shape) for p in self.parameter_list()]
             if got != self._plan.shapes:
                 raise RuntimeError(f"parameter inventory differs from the library's: {got} vs {self._plan.shapes}")
@@ -317,8 +334,10 @@ class ViT(nn.Module):
         self._check_embedders()
         mapper = self._is_mapper(self.x_embedder)
         xlin = self.x_embedder[2] if mapper else self.x_embedder
+        cmapper = self._is_c_mapper(self.c_embedder)
+        cseq = self.c_embedder[2] if cmapper else self.c_embedder
         ps = [self.pos_embed_freqs, xlin.weight, xlin.bias,
-              self.c_embedder[0].weight, self.c_embedder[0].bias, self.c_embedder[2].weight, self.c_embedder[2].bias,
+              cseq[0].weight, cseq[0].bias, cseq[2].weight, cseq[2].bias,
               self.t_embedder.mlp[0].weight, self.t_embedder.mlp[0].bias, self.t_embedder.mlp[2].weight, self.t_embedder.mlp[2].bias]
         for b in self.blocks:
             ps += [b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias, b.mlp.fc1.weight, b.mlp.fc1.bias,
@@ -327,6 +346,8 @@ class ViT(nn.Module):
                self.final_layer.adaLN_modulation[1].weight, self.final_layer.adaLN_modulation[1].bias]
         if mapper:  # the C ABI takes the mapper's two tensors last (include/vit4hep_hip.h: v4h_config.x_embed_in)
             ps += [self.x_embedder[0].weight, self.x_embedder[0].bias]
+        if cmapper:  # ... and the condition mapper's after them (v4h_config.c_embed_in)
+            ps += [self.c_embedder[0].weight, self.c_embedder[0].bias]
         return ps
 
     def inference_workspace(self, B, device):

@@ -34,7 +34,7 @@ class CFMTrainer:
 
         self.model = model
         self.net = model._core() if hasattr(model, "_core") else _unwrap(model.net)  # _core() (re)binds the wrapper's geometry to the net
-        if self.net.x_embed_in():
+        if self.net.x_embed_in() or self.net.c_embed_in():
             raise NotImplementedError("CFMTrainer: networks with a fine-tuning embedding mapper train through the autograd node and a torch optimizer "
                                       "(per-module learning rates, experiment_finetuning.py:173-205)")
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
