@@ -349,11 +349,11 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     }
     w.glin = (float*)take((size_t)p.Ppad * D * 4);
     w.glinb = (float*)take((size_t)p.Ppad * 4);
+    w.G = (float*)take((size_t)p.T * D * 4);  // batch sum of d x0 (positional-table backward): accumulated with atomics
     w.zero_bytes = off - z0;
     w.dxA = (float*)take(BT * D * 4);
     w.dxB = (float*)take(BT * D * 4);
     w.delta = (float*)take((size_t)B * p.H * p.T * 4);
-    w.G = (float*)take((size_t)p.T * D * 4);
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
     if (p.mapper()) w.dxpre = take(BT * p.Pxpad * es);
