@@ -82,6 +82,9 @@ size_t v4h_plan_workspace_bytes(const v4h_plan* plan, int32_t B, int32_t trainin
  *             The ODE sampler calls the network 80 times per batch with frozen weights (calochallenge_cfm/model.py:81-92). */
 #define V4H_FWD_TRAINING 1
 #define V4H_FWD_REUSE_OPERANDS 2
+/* V4H_FWD_SAME_CONDITION (inference, together with REUSE_OPERANDS): d_c holds the same values as in the previous call on this workspace -
+ * the c_embedder term of the conditioning (independent of t) is kept instead of recomputed.                                    */
+#define V4H_FWD_SAME_CONDITION 4
 int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
                         float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream, const int32_t* d_patch_map,
                         const float* d_pos);

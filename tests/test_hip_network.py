@@ -168,6 +168,39 @@ def test_frozen_weight_operand_copies_are_reused_and_invalidated():
     assert not torch.equal(before, after)
 
 
+def test_condition_embedding_is_kept_across_evaluations_of_the_same_conditions():
+    """V4H_FWD_SAME_CONDITION: the ODE solver evaluates the network many times for one condition tensor; the c_embedder term (independent
+    of t) is computed once.  Another tensor, an in-place write or changed weights recompute it."""
+    cfg = O.ds2(2)
+    fill = O.golden_fill(cfg)
+    for mode in ("f32", "bf16"):
+        model = U.build_models(cfg, mode, fill).eval()
+        net = model.net
+        x, c, _ = O.synthetic_batch(cfg, 4, 3)
+        x, c = x.to(U.DEV), c.to(U.DEV)
+        t1, t2 = torch.full((4, 1), 0.3, device=U.DEV), torch.full((4, 1), 0.7, device=U.DEV)
+        with torch.no_grad():
+            model.forward(x, t1, c)
+            assert net._last_fwd_flags == 0
+            a = model.forward(x, t2, c)          # same conditions, other time
+            assert net._last_fwd_flags == 2 | 4
+            c2 = c.clone()
+            b = model.forward(x, t2, c2)         # equal values, other tensor: recomputed
+            assert net._last_fwd_flags == 2 and torch.equal(a, b)
+            c2[:, 0] += 1.0                      # in-place write: recomputed
+            d = model.forward(x, t2, c2)
+            assert net._last_fwd_flags == 2 and not torch.equal(a, d)
+            e = model.forward(x, t2, c2)
+            assert net._last_fwd_flags == 2 | 4 and torch.equal(d, e)
+            fresh = U.build_models(cfg, mode, fill).eval()
+            assert torch.equal(d, fresh.forward(x, t2, c2))
+            net.c_embedder[2].bias.add_(0.5)     # weights changed: operands and the condition term are refreshed
+            f = model.forward(x, t2, c2)
+            assert net._last_fwd_flags == 0 and not torch.equal(e, f)
+        s1 = model.sample_batch(c)               # the whole sampler: flag set from the second evaluation on
+        assert net._last_fwd_flags == 2 | 4 and torch.isfinite(s1).all()
+
+
 @pytest.mark.parametrize("name", ["ds2_d2_b2", "ds2_d6_b2"])
 def test_update_step_trajectory_vs_golden(name, golden):
     """_step semantics (base_experiment.py:555-597) with the fused clip + AdamW kernels: loss trajectory and final weights."""

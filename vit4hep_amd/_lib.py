@@ -220,7 +220,7 @@ class Plan:
             pass
 
 
-FWD_TRAINING, FWD_REUSE_OPERANDS, ENERGY_SAME_CONDITION, ENERGY_COMPOSED = 1, 2, 4, 8  # flag bits of include/vit4hep_hip.h
+FWD_TRAINING, FWD_REUSE_OPERANDS, FWD_SAME_CONDITION, ENERGY_SAME_CONDITION, ENERGY_COMPOSED = 1, 2, 4, 4, 8  # flag bits of include/vit4hep_hip.h
 
 
 class EnergyPlan:

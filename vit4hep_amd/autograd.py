@@ -51,6 +51,11 @@ def run_forward(net, params, x_vox, t, c, training, ws=None):
             ws = net.inference_workspace(B, dev)
             if net.operands_current(params, ws):
                 flags |= 2  # V4H_FWD_REUSE_OPERANDS
+                if net.condition_current(c, ws):
+                    flags |= 4  # V4H_FWD_SAME_CONDITION: the ODE solver's evaluations of one batch share their conditions
+            else:
+                net.condition_current(c, ws)  # remember these conditions: their embedding is (re)computed by this call
+    net._last_fwd_flags = flags  # introspection (tests)
     out = torch.zeros_like(x_vox) if net.map_has_holes() else torch.empty_like(x_vox)
     tab = _lib.pointer_table(params)
     pmap, pos = net.device_tables(dev)

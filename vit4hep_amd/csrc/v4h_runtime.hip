@@ -228,7 +228,7 @@ struct WS {
   char *xp, *temb, *ht, *cpad, *hc, *silu_c, *uf;
   char *xpm, *xmb_pad, *dxpre;   // embedding mapper (fine-tuning): gathered input patches, padded bias, gradient of the pre-activation
   float *xpre, *gxmw, *gxmb;
-  float *pe, *ht_pre, *hc_pre, *cond, *modf, *meanf, *rstdf;
+  float *pe, *ht_pre, *hc_pre, *cond, *cemb, *modf, *meanf, *rstdf;
   float *mod_all, *adaB;   // every adaLN modulation of the step in one table (B x ldmod); concatenated adaLN biases
   char* adaW;              // concatenated operand copies of the adaLN weights (ldmod x D), bf16 mode: one contraction makes the whole table
   std::vector<float*> mod, X;
@@ -304,6 +304,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   w.hc_pre = (float*)take((size_t)B * D * 4);
   w.hc = take((size_t)B * D * es);
   w.cond = (float*)take((size_t)B * D * 4);
+  w.cemb = (float*)take((size_t)B * D * 4);  // c_embedder output (kept across evaluations with the same conditions)
   w.silu_c = take((size_t)B * D * es);
   w.mod.resize(p.depth);
   w.mod_all = (float*)take((size_t)B * p.ldmod() * 4);
@@ -452,7 +453,9 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   const int32_t flags = training;
   training = flags & 1;
   const bool reuse = (flags & V4H_FWD_REUSE_OPERANDS) != 0;  // operand copies + positional table of these parameters are already in this workspace
-  V4H_CHECK_ARG((flags & ~3) == 0, "vit_forward: unknown flag bits 0x%x", flags);
+  const bool same_c = (flags & V4H_FWD_SAME_CONDITION) != 0;  // ... and so is the condition embedding of these conditions
+  V4H_CHECK_ARG((flags & ~7) == 0, "vit_forward: unknown flag bits 0x%x", flags);
+  V4H_CHECK_ARG(!same_c || (reuse && !training), "vit_forward: V4H_FWD_SAME_CONDITION needs V4H_FWD_REUSE_OPERANDS and an inference call");
   RUN(check_common(p, B, params, ws, ws_bytes, training != 0, "vit_forward"));
   RUN(check_geom(p, pmap, pos, "vit_forward"));
   V4H_CHECK_ARG(x && t && cnd && out, "vit_forward: null tensor");
@@ -483,9 +486,10 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     }
     if (!reuse && p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
     if (!reuse && p->cmapper()) items.push_back(CastPadItem{c.pf(p->cmb()), w.cmb_pad, 1, p->Kc, 1, p->Kcpad, 1});
-    if (p->cmapper()) items.push_back(CastPadItem{cnd, w.cin, B, p->Kcx, B, p->Kcxpad, 0});
+    if (same_c) {}
+    else if (p->cmapper()) items.push_back(CastPadItem{cnd, w.cin, B, p->Kcx, B, p->Kcxpad, 0});
     else items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
-    RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
+    if (!items.empty()) RUN(cast_pad_many(m, items.data(), (int)items.size(), c.s));
   }
   // The token path (to_patches, positional table, x_embedder) and the conditioning path (t/c embedders, adaLN table) are
   // independent chains of small launch-latency-bound kernels until the first block: they run side by side.
@@ -510,25 +514,29 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T;
     RUN(gemm_fwd(m, EPI_EMBED, a, c.s));
   }
-  // 4-8. t_embedder, c_embedder, cond = t_emb + c_emb, silu(cond) (nn/vit.py:197-199)
-  RUN(timestep_embed(m, t, w.temb, B, p->F, cs));
+  // 4-8. c_embedder, t_embedder, cond = t_emb + c_emb, silu(cond) (nn/vit.py:197-199).  The condition term does not depend on t: a caller
+  // that evaluates the network again for the same conditions (the ODE solver: 80 times per batch) says so and it is kept.
   {
-    GemmArgs a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
+    GemmArgs a;
+    if (!same_c) {
+      if (p->cmapper()) {  // fine-tuning condition mapper: c' = silu(c Wm^T + bm)   (experiment_finetuning.py:106-119)
+        a = gargs(w.cin, p->Kcxpad, c.W(p->cmw()), p->Kcxpad, B, p->Kcpad, p->Kcxpad);
+        a.e.out = w.cpad; a.e.ldo = p->Kcpad; a.e.out2 = training ? w.cpre : nullptr; a.e.ldo2 = p->Kcpad; a.e.bias = (const float*)w.cmb_pad;
+        RUN(gemm_fwd(m, EPI_SILU, a, cs));
+      }
+      a = gargs(w.cpad, p->Kcpad, c.W(P_C0W), p->Kcpad, B, D, p->Kcpad);
+      a.e.out = w.hc; a.e.ldo = D; a.e.out2 = w.hc_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_C0B);
+      RUN(gemm_fwd(m, EPI_SILU, a, cs));
+      a = gargs(w.hc, D, c.W(P_C2W), D, B, D, D);
+      a.e.out = w.cemb; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B);  // (silu_c: overwritten below)
+      RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
+    }
+    RUN(timestep_embed(m, t, w.temb, B, p->F, cs));
+    a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
     a.e.out = w.ht; a.e.ldo = D; a.e.out2 = w.ht_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_T0B);
     RUN(gemm_fwd(m, EPI_SILU, a, cs));
     a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
-    a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B);
-    RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
-    if (p->cmapper()) {  // fine-tuning condition mapper: c' = silu(c Wm^T + bm)   (experiment_finetuning.py:106-119)
-      a = gargs(w.cin, p->Kcxpad, c.W(p->cmw()), p->Kcxpad, B, p->Kcpad, p->Kcxpad);
-      a.e.out = w.cpad; a.e.ldo = p->Kcpad; a.e.out2 = training ? w.cpre : nullptr; a.e.ldo2 = p->Kcpad; a.e.bias = (const float*)w.cmb_pad;
-      RUN(gemm_fwd(m, EPI_SILU, a, cs));
-    }
-    a = gargs(w.cpad, p->Kcpad, c.W(P_C0W), p->Kcpad, B, D, p->Kcpad);
-    a.e.out = w.hc; a.e.ldo = D; a.e.out2 = w.hc_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_C0B);
-    RUN(gemm_fwd(m, EPI_SILU, a, cs));
-    a = gargs(w.hc, D, c.W(P_C2W), D, B, D, D);
-    a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B); a.e.resid = w.cond; a.e.ld_resid = D;
+    a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B); a.e.resid = w.cemb; a.e.ld_resid = D;
     RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
   }
   // 9. every adaLN modulation of the step (nn/vit.py:323-330, 345-348)

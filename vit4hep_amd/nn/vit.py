@@ -310,7 +310,7 @@ class ViT(nn.Module):
         key = (T, P, int(self.condition_dim), int(self.final_layer.linear.weight.shape[0]), g[0], tuple(g[1]) if g[0] == "grid" else g[2], id(self._patch_map),
                self.x_embed_in(), self.c_embed_in())
         if self._plan is not None and getattr(self, "_plan_key", None) != key:  # embedders / head / position buffers were re-shaped
-            self._plan, self._infer_ws, self._dev_tables, self._infer_sig = None, {}, None, None
+            self._plan, self._infer_ws, self._dev_tables, self._infer_sig, self._infer_c = None, {}, None, None, None
         if self._plan is None:
             if int(self.final_layer.linear.weight.shape[0]) != P * int(self.out_channels):
                 raise ValueError(f"final_layer emits {int(self.final_layer.linear.weight.shape[0])} features per token, x_embedder takes {P}")
@@ -356,6 +356,7 @@ class ViT(nn.Module):
         if ws is None:
             self._infer_ws = {key: torch.empty(self._get_plan().workspace_bytes(B, False), dtype=torch.uint8, device=device)}
             self._infer_sig = None
+            self._infer_c = None
             ws = self._infer_ws[key]
         return ws
 
@@ -367,6 +368,21 @@ class ViT(nn.Module):
         same = getattr(self, "_infer_sig", None) == sig
         if mark:
             self._infer_sig = sig
+        return same
+
+    def condition_current(self, c, ws):
+        """True when the previous inference call on `ws` embedded exactly these conditions: the same tensor object (held weakly), not written
+        in place since (``_version``).  Only meaningful together with ``operands_current`` (the c_embedder weights must be unchanged too)."""
+        import weakref
+
+        try:
+            sig = (ws.data_ptr(), c.data_ptr(), c._version, tuple(c.shape))
+        except RuntimeError:  # inference tensors do not track versions: never assume
+            self._infer_c = None
+            return False
+        prev = getattr(self, "_infer_c", None)
+        same = prev is not None and prev[0]() is c and prev[1] == sig
+        self._infer_c = (weakref.ref(c), sig)
         return same
 
     # ------------------------------------------------------------------ forward
