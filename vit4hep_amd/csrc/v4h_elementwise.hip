@@ -175,7 +175,19 @@ template <typename T> __global__ void sum_over_batch_kernel(const T* __restrict_
 #pragma unroll
   for (int k = 0; k < 8; ++k) atomicAdd(G + i8 + k, s.v[k]);
 }
+// any width: one thread per feature (G zeroed by the caller as well)
+template <typename T> __global__ void sum_over_batch_scalar_kernel(const T* __restrict__ dx0, float* __restrict__ G, int B, int TD) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= TD) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += to_f32(dx0[(long)b * TD + idx]);
+  G[idx] += s;
+}
 template <typename T> void sum_over_batch(const void* dx0, float* G, int B, int TD, hipStream_t s) {
+  if (TD % 8 != 0) {
+    hipLaunchKernelGGL(sum_over_batch_scalar_kernel<T>, dim3((TD + 255) / 256), dim3(256), 0, s, (const T*)dx0, G, B, TD);
+    return;
+  }
   const int nbx = (TD / 8 + 255) / 256;
   int chunks = (1024 + nbx - 1) / nbx;  // ~1000 workgroups
   if (chunks > B) chunks = B;
@@ -572,7 +584,6 @@ int pos_embed_fwd_pos(const float* freqs, const float* pos, float* pe, int T, in
 }
 int pos_embed_bwd_pos(Mode m, const void* dx0, const float* freqs, const float* pos, float* dfreqs, float* scratch, int B, int T, int D, hipStream_t s) {
   const int TD = T * D;
-  V4H_CHECK_ARG(TD % 8 == 0, "pos_embed_bwd: tokens * hidden_dim = %d must be a multiple of 8", TD);
   if (m == MODE_BF16) sum_over_batch<bf16>(dx0, scratch, B, TD, s);  // scratch: zeroed by the caller
   else sum_over_batch<float>(dx0, scratch, B, TD, s);
   V4H_CHECK_LAUNCH("pos_embed_bwd/sum");
@@ -589,7 +600,6 @@ int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipS
 }
 int pos_embed_bwd(Mode m, const void* dx0, const float* freqs, float* dfreqs, float* scratch, int B, const PatchGeom& g, int D, hipStream_t s) {
   const int TD = g.l * g.a * g.r * D;
-  V4H_CHECK_ARG(TD % 8 == 0, "pos_embed_bwd: tokens * hidden_dim = %d must be a multiple of 8", TD);
   if (m == MODE_BF16) sum_over_batch<bf16>(dx0, scratch, B, TD, s);  // scratch: zeroed by the caller
   else sum_over_batch<float>(dx0, scratch, B, TD, s);
   V4H_CHECK_LAUNCH("pos_embed_bwd/sum");
