@@ -690,6 +690,74 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         if (a.e.bias != nullptr && cok[it]) bias8[it] = load8(a.e.bias + jb + rcol[it]);
       }
     }
+    // EPI_DGELU (16-bit operands): the saved gelu' of the WHOLE wave tile is requested up front, as raw 16-byte chunks (TI * NIT * 4 VGPRs):
+    // one exposed round trip per tile instead of one per 16-row strip; the strips are then handled chunk by chunk (no staging arrays).
+    constexpr bool HOIST = C::EPI == EPI_DGELU && sizeof(typename C::TO) == 2 && C::DBG != 8;
+    if constexpr (HOIST) {
+      bf16x8 raw[C::TI][NIT];
+#pragma unroll
+      for (int x = 0; x < C::TI; ++x)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int ib = i0 + wi * C::WTI + x * 16;
+          if (cok[it] && ib + rrow[it] < a.I)
+            raw[x][it] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(ea.aux) + (size_t)(ib + rrow[it]) * ea.ld_aux + jb + rcol[it]);
+        }
+#pragma unroll
+      for (int x = 0; x < C::TI; ++x) {
+#pragma unroll
+        for (int y = 0; y < C::TJ; ++y) *reinterpret_cast<f32x4*>(strip + c * SLD + y * 16 + 4 * g) = acc[x][y];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const int ib = i0 + wi * C::WTI + x * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if (cok[it] && ib + rrow[it] < a.I) {
+            f32x8 v = make8(*reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it]), *reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it] + 4));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v.v[r] *= (float)raw[x][it][r];
+            store8(reinterpret_cast<typename C::TO*>(ea.out) + (size_t)(ib + rrow[it]) * ea.ldo + jb + rcol[it], v);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if constexpr (C::EPI == EPI_GATE_RESID && C::DBG != 8) {
+      // the f32 residual rows of the NEXT strip are requested before the current strip is processed (two buffers of NIT chunks)
+      f32x8 res[2][NIT];
+      auto request = [&](int x, f32x8* dst) {
+        const int ibx = i0 + wi * C::WTI + x * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (cok[it] && ibx + rrow[it] < a.I) dst[it] = load8(ea.resid + (size_t)(ibx + rrow[it]) * ea.ld_resid + jb + rcol[it]);
+      };
+      request(0, res[0]);
+#pragma unroll
+      for (int x = 0; x < C::TI; ++x) {
+#pragma unroll
+        for (int y = 0; y < C::TJ; ++y) *reinterpret_cast<f32x4*>(strip + c * SLD + y * 16 + 4 * g) = acc[x][y];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        if (x + 1 < C::TI) request(x + 1, res[(x + 1) & 1]);
+        const int ib = i0 + wi * C::WTI + x * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if (cok[it] && ib + rrow[it] < a.I) {
+            const int i = ib + rrow[it], j = jb + rcol[it];
+            const f32x8 v = add8(make8(*reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it]),
+                                       *reinterpret_cast<const f32x4*>(strip + rrow[it] * SLD + rcol[it] + 4)), bias8[it]);
+            const f32x8 gate = load8(ea.rowvec + (size_t)(i / ea.T) * ea.ld_rowvec + j);
+            if (ea.out2) store8(reinterpret_cast<typename C::TO*>(ea.out2) + (size_t)i * ea.ldo2 + j, v);
+            f32x8 xn = res[x & 1][it];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xn.v[r] += gate.v[r] * v.v[r];
+            store8(reinterpret_cast<float*>(ea.out) + (size_t)i * ea.ldo + j, xn);
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
 #pragma unroll
     for (int x = 0; x < C::TI; ++x) {
 #pragma unroll
@@ -713,6 +781,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_wave_barrier();
+    }
     }
   }
   if constexpr (C::COLSUM) {
