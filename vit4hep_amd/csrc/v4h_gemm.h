@@ -722,7 +722,7 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
       }
-    } else if constexpr (C::EPI == EPI_GATE_RESID && C::DBG != 8) {
+    } else if constexpr (C::EPI == EPI_GATE_RESID && sizeof(T) == 2 && C::DBG != 8) {  // (f32 mode: fragments twice the size, no registers to spare)
       // the f32 residual rows of the NEXT strip are requested before the current strip is processed (two buffers of NIT chunks)
       f32x8 res[2][NIT];
       auto request = [&](int x, f32x8* dst) {
