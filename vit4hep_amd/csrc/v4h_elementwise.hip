@@ -2,6 +2,8 @@
 // adaLN modulate (forward and backward, with the gate backward fused in), weight cast/pad, the CFM trajectory and
 // loss, gradient norm, AdamW and the ODE-solver vector updates.  All HBM-bound: vectorised 16-byte accesses where
 // the layout allows, one wave per LayerNorm row, wavefront-shuffle row reductions, f32 statistics.
+#include <stdlib.h>
+
 #include "v4h_ops.h"
 
 namespace v4h {
@@ -659,13 +661,15 @@ int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, flo
 int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s) {
   hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
   if (e != hipSuccess) { v4h_set_error("mse: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
-  hipLaunchKernelGGL(mse_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, v, target, loss, dv, n, 1.0f / (float)n);
+  hipLaunchKernelGGL(mse_kernel, dim3(nblocks(n, 1024, 256)), dim3(256), 0, s, v, target, loss, dv, n, 1.0f / (float)n);  // (same-address atomic per workgroup)
   V4H_CHECK_LAUNCH("mse");
   return V4H_OK;
 }
 int sq_norm_accum(const float* g, long n, float* out, hipStream_t s) {
   V4H_CHECK_ARG(((uintptr_t)g % 16) == 0, "sq_norm: gradient buffer must be 16-byte aligned");
-  hipLaunchKernelGGL(sq_norm_kernel, dim3(nblocks(n, 4096)), dim3(256), 0, s, g, n, out);
+  // One workgroup per CU: every workgroup ends with an atomic on the SAME address, ~9 ns each at the L2 - with 2048 workgroups that was half
+  // of the kernel (26 M floats: 35.1 us; 1024: 26.0; 512: 20.1; 256: 18.0 us = 5.8 TB/s; tools/experiments/sqnorm_time.py).
+  hipLaunchKernelGGL(sq_norm_kernel, dim3(nblocks(n, 4096, 256)), dim3(256), 0, s, g, n, out);
   V4H_CHECK_LAUNCH("sq_norm");
   return V4H_OK;
 }
