@@ -164,18 +164,29 @@ __global__ void pos_embed_fwd_kernel(const float* __restrict__ freqs, float* __r
 }
 // stage 1: G[n][d] += sum_b dx0[b][n][d]   (G zeroed by the caller).  A thread owns 8 consecutive features (one 16-byte load per sample in
 // bf16 mode) of a chunk of the batch (gridDim.y chunks: enough workgroups to fill the chip) and adds its partial sums with f32 atomics.
-// [one thread per feature looping over the whole batch with 2-byte loads: 35.7 us for 16.6 MB; this: see profiles]
+// [one thread per feature looping over the whole batch with 2-byte loads: 33-36 us for 16.6 MB]
 template <typename T> __global__ void sum_over_batch_kernel(const T* __restrict__ dx0, float* __restrict__ G, int B, int TD, int bchunk) {
   const int i8 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  if (i8 >= TD) return;
   const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
   f32x8 s;
 #pragma unroll
   for (int k = 0; k < 8; ++k) s.v[k] = 0.f;
+  if (i8 < TD) {
 #pragma unroll 4
-  for (int b = b0; b < b1; ++b) s = add8(s, load8(dx0 + (long)b * TD + i8));
+    for (int b = b0; b < b1; ++b) s = add8(s, load8(dx0 + (long)b * TD + i8));
+  }
+  // float atomics run at full rate only when a wave-instruction covers consecutive addresses (a lane adding its own 8 consecutive sums makes
+  // every instruction a stride-8 scatter: 61 us instead of 33 for the kernel this one replaced): re-order the block's 2048 sums through LDS
+  __shared__ float sm[256 * 8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) atomicAdd(G + i8 + k, s.v[k]);
+  for (int k = 0; k < 8; ++k) sm[threadIdx.x * 8 + k] = s.v[k];
+  __syncthreads();
+  const int base = blockIdx.x * blockDim.x * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = k * 256 + threadIdx.x;
+    if (base + idx < TD) atomicAdd(G + base + idx, sm[idx]);
+  }
 }
 // any width: one thread per feature (G zeroed by the caller as well)
 template <typename T> __global__ void sum_over_batch_scalar_kernel(const T* __restrict__ dx0, float* __restrict__ G, int B, int TD) {
