@@ -471,6 +471,11 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
   const int ntiles = (Tn + 15) / 16;
   const bool active = wave < ntiles;
   const int row = wave * 16 + c;  // this lane's lane-side row: a query in phase 1, a key in phase 2
+  // The element-wise work between the products is what the busiest SIMD (3 of the 9 waves) spends most of its time on, so it is kept to
+  // p = exp2(s * c2 - lse * log2e), ds = p * (dp * scale - delta * scale): two FMAs, one exponential, one multiply per score; the mask of
+  // the streamed rows >= T only where a tile can contain such rows.
+  const float c2 = scale * 1.4426950408889634f;
+  const int full_tiles = Tn / 16;  // streamed tiles jt < full_tiles hold valid rows only
   auto kfrag = [&](const T* img, int jt, int s2) {  // regs-side fragment of streamed rows jt*16.. from a dense image, zero beyond head_dim
     Frag<T> f = frag_kcontig(img, DH, jt * 16, 32 * s2, lane);
     if (32 * s2 + 8 * g + 8 > DH) f = frag_zero<T>();
@@ -497,6 +502,18 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
     DI::stage(iK, base + D, ld, Tn, wave, NW, lane);
     DI::stage(iV, base + 2 * D, ld, Tn, wave, NW, lane);
   }
+  f32x4 dk[C::NDT], dv[C::NDT];  // results of phase 2: stored after the NEXT barrier (see the note at barrier B)
+  int pend = -1;                 // item whose dK, dV are still in registers
+  auto store_dkv = [&](int item) {
+    if (active && row < Tn) {
+      T* out = dqkv + ((size_t)(item / H) * Tn + row) * ld + (item % H) * DH;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        store4(out + D + dt * 16 + 4 * g, dk[dt]);
+        store4(out + 2 * D + dt * 16 + 4 * g, dv[dt]);
+      }
+    }
+  };
   for (; it < nitems; it += gridDim.x) {
     const int b = it / H, h = it % H;
     const T* base = qkv + (size_t)b * Tn * ld + h * DH;
@@ -516,18 +533,20 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
       delta_q += __shfl_xor(delta_q, 16, 64);
       delta_q += __shfl_xor(delta_q, 32, 64);
     }
-    if (active && row < Tn) lse_q = lse[((size_t)b * H + h) * Tn + row];
+    if (active && row < Tn) lse_q = lse[((size_t)b * H + h) * Tn + row] * 1.4426950408889634f;  // in units of log 2
+    const float delta_s = delta_q * scale;
     __syncthreads();  // (A) K and V of this item have landed; nobody reads the previous item's Q / dO images, lse or delta any more
+    if (pend >= 0) store_dkv(pend);
     DI::stage(iQ, base, ld, Tn, wave, NW, lane);
     DI::stage(iDO, dobase, D, Tn, wave, NW, lane);
     if (active && g == 0) {
-      sLse[row] = lse_q;      // rows >= Tn hold 0 (masked in phase 2)
-      sDelta[row] = row < Tn ? delta_q : 0.f;
+      sLse[row] = lse_q;      // (log-2 units) rows >= Tn hold 0 (masked in phase 2)
+      sDelta[row] = row < Tn ? delta_s : 0.f;  // delta * scale
     }
-    if (active) {
-      f32x4 dq[C::NDT];
+    f32x4 dq[C::NDT];
 #pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
 #pragma unroll
       for (int ks = 0; ks < C::NJT / 2; ++ks) {  // two key tiles at a time: scores -> dS -> straight into dQ
         f32x4 ds2[2];
@@ -538,17 +557,12 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
           const f32x4 dp = scores(sV, jt, xdo);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = jt * 16 + 4 * g + r;
-            const float pr = (key < Tn && row < Tn) ? __expf(sc[r] * scale - lse_q) : 0.f;
-            ds2[hh][r] = pr * (dp[r] - delta_q) * scale;
+            float pr = __builtin_amdgcn_exp2f(sc[r] * c2 - lse_q);
+            if (jt >= full_tiles && jt * 16 + 4 * g + r >= Tn) pr = 0.f;  // key rows beyond the sequence (zero rows of the image)
+            ds2[hh][r] = pr * (dp[r] * scale - delta_s);
           }
         }
         accumulate(dq, ds2[0], ds2[1], sK, ks);
-      }
-      if (row < Tn) {
-        T* out = dqkv + ((size_t)b * Tn + row) * ld + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) store4(out + dt * 16 + 4 * g, dq[dt]);
       }
     }
     // lane-side operands of phase 2: this wave's 16 key rows, from the K / V images (rows >= T are zero) before the next item's DMA overwrites them
@@ -559,6 +573,13 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
       xv[s2] = kfrag(sV, wave, s2);
     }
     __syncthreads();  // (B) Q and dO have landed, lse / delta are complete; every wave holds its K / V fragments, the images are free
+    // results are stored AFTER the barrier that follows their phase: a barrier drains the memory counter (loads, DMA and stores alike), so a
+    // store issued just before it is a full round trip of waiting for all nine waves; issued here it completes under the next phase
+    if (active && row < Tn) {
+      T* out = dqkv + ((size_t)b * Tn + row) * ld + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) store4(out + dt * 16 + 4 * g, dq[dt]);
+    }
     if (it + (int)gridDim.x < nitems) {
       const int nx = it + gridDim.x;
       const T* nbase = qkv + (size_t)(nx / H) * Tn * ld + (nx % H) * DH;
@@ -566,13 +587,12 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
       DI::stage(iV, nbase + 2 * D, ld, Tn, wave, NW, lane);
     }
     // ---- phase 2: dK, dV
-    if (active) {
-      f32x4 dk[C::NDT], dv[C::NDT];
 #pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt) {
-        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (active) {
 #pragma unroll
       for (int ks = 0; ks < C::NJT / 2; ++ks) {  // two query tiles at a time: P^T, dS^T -> straight into dV, dK
         f32x4 pt2[2], dst2[2];
@@ -585,25 +605,19 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
           const f32x4 de = *reinterpret_cast<const f32x4*>(sDelta + jt * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qq = jt * 16 + 4 * g + r;
-            const float pr = (qq < Tn && row < Tn) ? __expf(sc[r] * scale - ls[r]) : 0.f;
+            float pr = __builtin_amdgcn_exp2f(sc[r] * c2 - ls[r]);
+            if (jt >= full_tiles && jt * 16 + 4 * g + r >= Tn) pr = 0.f;  // query rows beyond the sequence
             pt2[hh][r] = pr;
-            dst2[hh][r] = pr * (dp[r] - de[r]) * scale;
+            dst2[hh][r] = pr * (dp[r] * scale - de[r]);
           }
         }
         accumulate(dv, pt2[0], pt2[1], sDO, ks);
         accumulate(dk, dst2[0], dst2[1], sQ, ks);
       }
-      if (row < Tn) {
-        T* out = dqkv + ((size_t)b * Tn + row) * ld + h * DH;
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) {
-          store4(out + D + dt * 16 + 4 * g, dk[dt]);
-          store4(out + 2 * D + dt * 16 + 4 * g, dv[dt]);
-        }
-      }
     }
+    pend = it;
   }
+  if (pend >= 0) store_dkv(pend);
 }
 
 template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
