@@ -186,6 +186,11 @@ int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const 
  * operand is stored [k][idx].  out is `mode`-typed unless out_f32 != 0.  nn.Linear forward/dgrad/wgrad. */
 int32_t v4h_op_gemm(int32_t mode, const void* d_P, int32_t ldp, int32_t p_kstrided, const void* d_Q, int32_t ldq, int32_t q_kstrided, const float* d_bias,
                     void* d_out, int32_t ldo, int32_t out_f32, int32_t I, int32_t J, int32_t K, int32_t splitk, float* d_colsum, void* stream);
+/* Weight gradient as the backward pass computes it: out[i][j] += sum_k P[k][i] Q[k][j] (both operands token-major), split-K partials
+ * into d_slab (f32, at least splitk * I * J elements) with plain stores, then one ordered reduction (bit-reproducible); optional
+ * d_colsum[i] += sum_k P[k][i] (the bias gradient).  nn.Linear wgrad, reference nn/vit.py:416,420 + timm Mlp :317-322. */
+int32_t v4h_op_gemm_wgrad_slab(int32_t mode, const void* d_P, int32_t ldp, const void* d_Q, int32_t ldq, float* d_slab, float* d_out, int32_t I, int32_t J,
+                               int32_t K, int32_t splitk, float* d_colsum, void* stream);
 /* softmax(q k^T / sqrt(dh)) v on token-major qkv (B*T, 3*H*dh) -> o (B*T, H*dh), lse (B,H,T)   nn/vit.py:425-451 */
 int32_t v4h_op_attention_fwd(int32_t mode, const void* d_qkv, void* d_o, float* d_lse, int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
 int32_t v4h_op_attention_bwd(int32_t mode, const void* d_qkv, const void* d_o, const void* d_do, const float* d_lse, float* d_delta, void* d_dqkv,

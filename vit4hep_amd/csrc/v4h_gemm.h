@@ -272,8 +272,11 @@ template <typename T, int CPR> V4H_DEV int sw_kcontig(int row) {
   else if constexpr (sizeof(T) == 2) return row & (CPR - 1) & 6;
   else return ((row >> 1) & 1) | (row & 4);
 }
-template <typename T> V4H_DEV int sw_kstrided(int k) {
-  if constexpr (sizeof(T) == 2) return (k & 8) >> 2;
+// (rows of a multiple of 256 bytes - CPR % 16 == 0 - all start on the same bank, so the four rows q of a transposed read must be
+// spread by (k & 3) as well: pos = chunk ^ 2 * ((k & 3) | ((k >> 1) & 4)), conflict-free by tools/lds_model.py)
+template <typename T, int CPR = 0> V4H_DEV int sw_kstrided(int k) {
+  if constexpr (sizeof(T) == 2 && CPR > 0 && CPR % 16 == 0) return 2 * ((k & 3) | ((k >> 1) & 4));
+  else if constexpr (sizeof(T) == 2) return (k & 8) >> 2;
   else return 0;
 }
 
@@ -356,7 +359,7 @@ template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
 #pragma unroll
     for (int n = 0; n < NPW; ++n) {
       const int u = (wave + n * NW) * 64 + lane, row = u / CPR, pos = u % CPR;
-      const int gi = idx0 + (pos ^ sw_kstrided<T>(row)) * CH;
+      const int gi = idx0 + (pos ^ sw_kstrided<T, CPR>(row)) * CH;
       krow[n] = row;
       src[n] = reinterpret_cast<const char*>(g + (size_t)(kb + row) * ld + (gi + CH <= idx_end ? gi : 0));
     }
@@ -388,8 +391,8 @@ template <typename T, int COLS, int BK, int NW> struct ImgKStrided {
     if constexpr (sizeof(T) == 2) {
       const int q = (lane >> 2) & 3, p = lane & 3;
       const int ch = (idx0 + 4 * p) / 8, r0 = kk + 8 * g + q, r1 = r0 + 4;
-      const bf16x4 lo = lds_tr_read(reinterpret_cast<const bf16*>(img + (r0 * CPR + (ch ^ sw_kstrided<T>(r0))) * 16 + 8 * (p & 1)));
-      const bf16x4 hi = lds_tr_read(reinterpret_cast<const bf16*>(img + (r1 * CPR + (ch ^ sw_kstrided<T>(r1))) * 16 + 8 * (p & 1)));
+      const bf16x4 lo = lds_tr_read(reinterpret_cast<const bf16*>(img + (r0 * CPR + (ch ^ sw_kstrided<T, CPR>(r0))) * 16 + 8 * (p & 1)));
+      const bf16x4 hi = lds_tr_read(reinterpret_cast<const bf16*>(img + (r1 * CPR + (ch ^ sw_kstrided<T, CPR>(r1))) * 16 + 8 * (p & 1)));
       f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     } else {
       const int col = idx0 + (lane & 15);

@@ -2,6 +2,7 @@
 #include <stdlib.h>
 
 #include "v4h_ops.h"
+#include "v4h_gemm2.h"
 
 namespace v4h {
 namespace {
@@ -83,7 +84,25 @@ template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream
   return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, 32, 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
 }
 
+// ---- 256 x 160 / 8-wave / three-stage kernel (v4h_gemm2.h): bf16, token-sized contractions ----
+int g_v2 = env_flag("V4H_GEMM2", 0);  // off by default: measured slower than the two-workgroup kernel on 7 of 8 block shapes (profiles/r02_gemm2_ablation.md)
+inline bool v2_ok(const GemmArgs& a, int klen) {
+  return g_v2 && a.I >= 2048 && a.J % 160 == 0 && klen >= 192 && a.e.ldo % 8 == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 4 < 0x7FFFFFF0L;
+}
+
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (v2_ok(a, a.K)) {
+      if (epi == EPI_STORE && g_v2 == 2) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1>>(a, 1, s, "gemm2_fwd/store/dbg1");
+      if (epi == EPI_STORE && g_v2 == 3) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2>>(a, 1, s, "gemm2_fwd/store/dbg2");
+      if (epi == EPI_STORE && g_v2 == 4) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 3>>(a, 1, s, "gemm2_fwd/store/dbg3");
+      if (epi == EPI_STORE && g_v2 == 5) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 7>>(a, 1, s, "gemm2_fwd/store/dbg7");
+      if (epi == EPI_STORE && g_v2 == 6) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 11>>(a, 1, s, "gemm2_fwd/store/dbg11");
+      if (epi == EPI_STORE && g_v2 == 7) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 15>>(a, 1, s, "gemm2_fwd/store/dbg15");
+      if (epi == EPI_STORE) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
+      if (epi == EPI_GELU && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
+    }
+  }
   switch (epi) {
     case EPI_STORE: return run_store_cfg<T, false>(a, s, "gemm_fwd/store");
     case EPI_STORE_F32: return run<T, T, false, false, 128, 160, EPI_STORE_F32>(a, 1, s, "gemm_fwd/store_f32");
@@ -105,6 +124,12 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (v2_ok(a, a.K)) {
+      if (epi == EPI_STORE) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
+      if (epi == EPI_DGELU && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");
+    }
+  }
   switch (epi) {
     case EPI_STORE: return run_store_cfg<T, true>(a, s, "gemm_dgrad/store");
     case EPI_DGELU:
@@ -134,10 +159,14 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + bk - 1) / bk * bk;
   *nz_out = (a.K + klen - 1) / klen;
+  if (m == MODE_BF16 && g_v2 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
+    return v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 160, 96, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
   return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
 }
 
-void debug_set_gemm_cfg(int cfg, int cfg_wgrad) { g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad % 100; g_big = cfg_wgrad / 100 ? 0 : 1; }
+void debug_set_gemm_cfg(int cfg, int cfg_wgrad) {
+  if (cfg_wgrad >= 1000) { g_v2 = cfg_wgrad / 1000 - 1; cfg_wgrad %= 1000; }
+  g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad % 100; g_big = cfg_wgrad / 100 ? 0 : 1; }
 
 }  // namespace v4h

@@ -873,6 +873,15 @@ extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t
   v4h_set_error("op_gemm: layout (P K-strided, Q K-contiguous) is not used on the path and not built");
   return V4H_ERR_UNSUPPORTED;
 }
+extern "C" int32_t v4h_op_gemm_wgrad_slab(int32_t mode, const void* P, int32_t ldp, const void* Q, int32_t ldq, float* slab, float* out, int32_t I, int32_t J, int32_t K,
+                                          int32_t splitk, float* colsum, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && P && Q && slab && out && splitk >= 1, "op_gemm_wgrad_slab: bad argument");
+  GemmArgs a = gargs(P, ldp, Q, ldq, I, J, K);
+  a.colsum = colsum;
+  int nz = 0;
+  if (int rc = gemm_wgrad_slab((Mode)mode, a, splitk, slab, &nz, (hipStream_t)s)) return rc;
+  return slab_reduce(slab, nz, (long)I * J, out, (hipStream_t)s);
+}
 extern "C" int32_t v4h_op_attention_fwd(int32_t mode, const void* qkv, void* o, float* lse, int32_t B, int32_t T, int32_t H, int32_t dh, void* s) {
   V4H_CHECK_ARG((mode == 0 || mode == 1) && qkv && o && B > 0 && T > 0 && H > 0, "op_attention_fwd: bad argument");
   return attention_fwd((Mode)mode, qkv, o, lse, B, T, H, dh, (hipStream_t)s);
