@@ -30,9 +30,27 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-# HBM bytes per update step from the PMC counters (separate rocprofv3 --pmc passes, tools/pmc_step.sh; FETCH_SIZE doubled
-# per MI355X_MICROARCH.md because the reads are 16-byte-per-lane streams, WRITE_SIZE as is): profiles/r01_step_hbm_traffic.txt
-MEASURED_HBM_BYTES_PER_STEP = {("ds2", "bf16"): 2 * 4.900e9 + 5.170e9}
+# HBM bytes per update step come from the PMC counters (separate rocprofv3 --pmc passes over THIS program, tools/pmc_step.sh; FETCH_SIZE
+# doubled per MI355X_MICROARCH.md because the reads are 16-byte-per-lane streams, WRITE_SIZE as is).  The profiling script writes
+# profiles/step_hbm_traffic.json together with the digest of the kernel sources it measured; a figure whose digest is not the digest of
+# the library being run is NOT reported (traffic: null) - a stale constant is worse than none.
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "step_hbm_traffic.json")
+
+
+def measured_traffic(workload, mode):
+    try:
+        from vit4hep_amd.build import _digest
+
+        with open(TRAFFIC_FILE) as fh:
+            rec = json.load(fh)
+        ent = rec.get(f"{workload}/{mode}")
+        if ent and ent.get("kernel_digest") == _digest():
+            return float(ent["bytes_per_step"]), None
+        return None, "profiles/step_hbm_traffic.json was measured on other kernel sources (digest mismatch): re-run tools/pmc_step.sh"
+    except (OSError, ValueError, KeyError) as e:
+        return None, f"no usable traffic file: {e}"
+
+
 BF16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3  # f32-input MFMA = vector rate
 
@@ -150,7 +168,74 @@ def op_rates(mode, BT, device, reps=20):
     return out
 
 
-def cpu_baseline(w, budget_s=20.0):
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one process per GPU, RCCL over xGMI) the way the reference's main.py:9-26
+    spawns its own, as CHILD processes of a parent that never touches the GPU, pass rank 0's JSON line through and return the children's code."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()  # (counting devices does not initialise the runtime)
+    if have < n:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith('{"metric"'):
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or not line:
+        print(f"bench.py: the {n}-rank run failed (rc {r.returncode})", file=sys.stderr)
+        return r.returncode or 1
+    print(line[-1], flush=True)
+    return 0
+
+
+def sampling_rates(model, w, device, peak, batch=256, reps=2):
+    """BASELINE config 5 (ds2 shape sampling, one GPU): CaloChallengeCFM.sample_batch (calochallenge_cfm/model.py:68-94) at the reference's
+    sampling batch of 256 with its default fixed-grid RK4 (step 0.05 = 80 network evaluations) and with Heun (40), timed after the training region."""
+    T, P = tokens_and_patch_dim(w)
+    flops = fwd_flops_per_sample(T, P, w["depth"], K=w["cond"])
+    _, c = synthetic(w["shape"], batch, 7, device, cond=w["cond"])
+    was_training = model.training
+    model.eval()
+    saved = model.odeint_kwargs
+    out = {"batch": batch, "workload": "ds2 shape sampling, bf16 network evaluations, conditions resident in HBM"}
+    for method, nfe in (("rk4", 80), ("heun2", 40)):
+        model.odeint_kwargs = {"method": method, "options": {"step_size": 0.05}}
+        model.sample_batch(c)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s = model.sample_batch(c)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert bool(torch.isfinite(s).all())
+        tf = nfe * batch * flops / dt / 1e12
+        out[method] = {"nfe": nfe, "showers_per_s": round(batch / dt, 1), "s_per_100k": round(1e5 / batch * dt, 2), "tflops": round(tf, 1), "frac": round(tf / peak, 4)}
+    model.odeint_kwargs = saved
+    model.train(was_training)
+    return out
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, budget_s=16.0):
     """The CPU oracle (kind 'port') timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import vit_cfm_oracle as O
 
@@ -174,8 +259,20 @@ def cpu_baseline(w, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
-    return {"value": round(n / el, 4), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full update steps of the same workload (B={B}, depth {depth}) with the PyTorch-CPU oracle, {el:.1f} s"}
+    rec = {"value": round(n / el, 4), "unit": "steps/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+           "sample": f"{n} full update steps of the same workload (B={B}, depth {depth}) with the PyTorch-CPU oracle, {el:.1f} s"}
+    # one thread, on a slice of the batch (a whole bs=128 step takes about a minute on one core): B/16 samples, scaled
+    torch.set_num_threads(1)
+    Bs = max(1, B // 16)
+    xs, cs, gs = O.synthetic_batch(cfg, Bs, 1)
+    ts, x0s = O.synthetic_noise(cfg, Bs, gs)
+    t1 = time.perf_counter()
+    O.train_step(O.golden_fill(cfg), O.AdamWState(), xs, cs, ts, x0s, cfg)
+    e1 = time.perf_counter() - t1
+    rec["one_thread"] = {"value": round(Bs / B / e1, 5), "unit": "steps/s", "cores": 1,
+                         "sample": f"one update step on {Bs} of the {B} samples ({e1:.1f} s), scaled to the full batch"}
+    torch.set_num_threads(threads)
+    return rec
 
 
 def main():
@@ -187,14 +284,15 @@ def main():
     ap.add_argument("--workload", default="ds2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-rates", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # before anything touches the GPU in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} ...")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
     torch.cuda.set_device(local_rank)
@@ -252,6 +350,7 @@ def main():
         dev_ms_step = dev_ms / args.steps
         achieved = flop_step / (dev_ms_step * 1e-3) / 1e12
         peak = BF16_DENSE_PEAK_TFLOPS if args.mode == "bf16" else F32_MFMA_PEAK_TFLOPS
+        traffic, traffic_note = measured_traffic(args.workload, args.mode)
         rec = {
             "metric": "CFM train steps/sec (ds2 shape ViT, bs=128)" if args.workload == "ds2" else f"CFM train steps/sec ({args.workload})",
             "value": round(world * args.steps / wall, 3),
@@ -270,12 +369,16 @@ def main():
                         "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
             "loss": round(float(loss), 5),
             "grad_norm": round(float(gn), 5),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": MEASURED_HBM_BYTES_PER_STEP.get((args.workload, args.mode)),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
+        if traffic_note:
+            rec["roofline"]["traffic_note"] = traffic_note
         if world == 1 and not args.no_op_rates:
             rec["gemm_ops"] = op_rates(args.mode, B * T, device)
+        if world == 1 and not args.no_sampling and args.workload == "ds2":
+            rec["sampling"] = sampling_rates(model, w, device, peak)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)
             rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)

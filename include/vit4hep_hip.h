@@ -2,7 +2,16 @@
  * luigifvr/vit4hep.  Plain pointers and sizes only; every pointer named d_* is a DEVICE pointer (HBM), `stream`
  * is a hipStream_t passed as void*.  All entry points return 0 on success, non-zero on error
  * (v4h_last_error() gives the message); none of them synchronises, allocates device memory or touches the host
- * copy of any tensor, so a caller may capture them into a hipGraph.
+ * copy of any tensor, so a caller may capture them into a hipGraph (the network entry points fork onto a side stream owned by the
+ * plan and join it again through events recorded on the caller's stream, which a capture follows; an inference forward is
+ * captured and replayed in tests/test_hip_round2.py).
+ *
+ * Threads and devices.  A v4h_plan is NOT thread-safe: it owns a side stream, a ring of events and their cursor, all mutated by
+ * every v4h_vit_forward / v4h_vit_backward* call, so calls on one plan must be serialised by the caller (one host thread per plan,
+ * or a lock); distinct plans may be used from distinct threads once each contraction variant has been launched at least once (the
+ * first launch of a variant sets its dynamic-LDS attribute without a lock) - warm up on one thread.  v4h_last_error() is
+ * per process, not per thread.  A plan binds to the device that is current at its first forward / backward call (side stream and
+ * events live there); later calls with another device current are rejected.  Environment switches (V4H_*) are read once.
  *
  * The reference has no native boundary of its own (pure Python): each entry point below replaces
  * the PyTorch/timm/xformers/torchdiffeq calls of the cited reference lines (paths relative to the reference
@@ -19,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 4
+#define V4H_ABI_VERSION 5
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -174,9 +183,12 @@ int32_t v4h_mse_loss(const float* d_v, const float* d_target, float* d_loss, flo
 /* sum of squares accumulated into d_out[0] (clip_grad_norm_, experiments/base_experiment.py:562-585) */
 int32_t v4h_sq_norm_accum(const float* d_g, int64_t n, float* d_out, void* stream);
 /* clip_grad_norm_(max_norm) + torch.optim.AdamW step on one flat tensor (experiments/base_experiment.py:573-592,
- * configs/training/default.yaml:5-10).  d_gnorm_sq may be NULL (no clipping).  step >= 1 is the AdamW step count. */
+ * configs/training/default.yaml:5-10).  step >= 1 is the AdamW step count.  With d_gnorm_sq given (max_norm = +inf for "no clipping", which is
+ * what the reference passes) a non-finite gradient norm leaves parameters and moments untouched and increments *d_nonfinite (optional, sticky,
+ * device memory): the reference raises at that point (clip_grad_norm_(error_if_nonfinite=True), base_experiment.py:573-585), the caller of
+ * this asynchronous form raises when it next looks at the flag.  d_gnorm_sq == NULL: no clipping and no guard. */
 int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, int32_t step, void* stream);
+                       float beta2, float eps, float weight_decay, int32_t step, void* stream, int32_t* d_nonfinite);
 /* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
 int32_t v4h_axpby(float* d_out, const float* d_a, const float* d_b, float alpha, float beta, int64_t n, void* stream);
 int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const float* d_k3, const float* d_k4, float h, int64_t n, void* stream);

@@ -265,6 +265,41 @@ def make_case(name, cfg, B, seed, sample_specs, train_steps, kind="calochallenge
     print(f"{name}: loss={loss.item():.6f} |g|={out['grad_total_norm']:.6f} nparams={nparams} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 
+def make_trajectory_case(name, cfg, B, seed, steps):
+    """BASELINE.json config 1: `steps` update steps of the reference's own CFM module on its CPU path (synthetic voxels; AdamW 1e-4 / wd 0.1,
+    CosineAnnealingLR over `steps`, clip 1000: configs/training/default.yaml, experiments/base_experiment.py:555-597).  Only the seeds and the
+    loss / gradient-norm trajectory are stored: the batch and the per-step (t, x_0) are regenerated by the test from the same seeded CPU
+    generators (oracle.synthetic_batch / synthetic_noise), which keeps the fixture at a few KiB."""
+    torch.manual_seed(1234)
+    model = build_reference(cfg)
+    load_fill(model, cfg)
+    model.train()
+    x, c, _ = O.synthetic_batch(cfg, B, seed)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=steps, eta_min=0)
+    gt = torch.Generator().manual_seed(seed + 300)
+    losses, gnorms = [], []
+    for _ in range(steps):
+        t_k, x0_k = O.synthetic_noise(cfg, B, gt)
+        x_t = (1 - t_k) * x0_k + t_k * x
+        vel = model.forward(x_t, t_k.view(-1, 1), c)
+        l_k = ((vel - (x - x0_k)) ** 2).mean()
+        opt.zero_grad(set_to_none=True)
+        l_k.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1000.0, error_if_nonfinite=True)
+        opt.step()
+        sched.step()
+        losses.append(l_k.item())
+        gnorms.append(gn.item())
+    sd = model.state_dict()
+    out = {"B": np.int64(B), "seed": np.int64(seed), "noise_seed": np.int64(seed + 300), "iters": np.int64(steps), "losses": np.array(losses), "gnorms": np.array(gnorms),
+           "x_checksum": np.float64(x.double().sum().item()), "final/blocks.1.mlp.fc2.weight": sd["net.blocks.1.mlp.fc2.weight"].numpy()[::16, ::64].copy(),
+           "final/pos_embed_freqs": sd["net.pos_embed_freqs"].numpy()}
+    path = os.path.join(REPO, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss {losses[0]:.6f} -> {losses[-1]:.6f} over {steps} steps -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
 def check_branches(cfg):
     """SDPA branch vs (stand-in) xformers branch of nn/vit.py:431-449 must agree."""
     a = build_reference(cfg, True)
@@ -438,13 +473,14 @@ def main():
     only = set(sys.argv[1:])  # optional: names of the cases to (re)generate
     if only:
         g = globals()
-        for fn in ("make_case", "make_energy_case", "make_mapper_case", "make_transforms_case"):
+        for fn in ("make_case", "make_energy_case", "make_mapper_case", "make_transforms_case", "make_trajectory_case"):
             g[fn] = (lambda f: lambda name, *a, **k: f(name, *a, **k) if name in only else None)(g[fn])
         g["check_branches"] = lambda *a, **k: None
     check_branches(O.ds2(2))
     make_case("ds2_d2_b2", O.ds2(2), 2, 11, [("rk4", "rk4", 0.05), ("heun", "heun2", 0.25)], 5)
     make_case("ds2_d6_b2", O.ds2(6), 2, 12, [("rk4_coarse", "rk4", 0.25)], 3)
     make_case("ds3_d6_b1", O.ds3(6), 1, 13, [("rk4_coarse", "rk4", 0.5)], 0)
+    make_trajectory_case("ds2_d2_b8_50it", O.ds2(2), 8, 61, 50)  # BASELINE.json configs[0]
     # the other ViT-CFM geometries: multi-segment patching + position buffers
     make_case("ds1_photons_d2_b3", O.ds1_photons(2), 3, 21, [("rk4_coarse", "rk4", 0.25)], 3, kind="ds1")
     make_case("ds1_pions_d2_b2", O.ds1_pions(2), 2, 22, [("heun", "heun2", 0.25)], 0, kind="ds1")

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_plan_inventory_matches_reference_state_dict():
@@ -225,3 +225,19 @@ def test_driver_build_entry_point():
 
     ge = importlib.import_module("__graft_entry__")
     ge.build()
+
+
+def test_bench_gpus_n_launches_its_own_ranks_or_fails_loudly():
+    """`python bench.py --gpus N` outside a launcher starts N child ranks itself (reference main.py:9-26 spawns its own); with fewer than N
+    GPUs visible - as here - it must fail with a non-zero code and a message, not exit quietly without a JSON line."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, r.stderr[-2000:]
+    else:
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '{"metric"' not in r.stdout

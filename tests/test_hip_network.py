@@ -130,8 +130,9 @@ def test_sample_batch_shape_and_determinism():
 
 
 def test_frozen_weight_operand_copies_are_reused_and_invalidated():
-    """Inference forwards keep the bf16 / padded operand copies of unchanged weights in the persistent workspace
-    (V4H_FWD_REUSE_OPERANDS); any in-place update of a parameter, by torch or by the fused trainer, refreshes them."""
+    """Inference forwards keep the bf16 / padded operand copies of the weights in the persistent workspace (V4H_FWD_REUSE_OPERANDS) only
+    inside a ``frozen_weights()`` scope (the ODE solve); outside, every forward recasts - so a write through ``p.data`` (EMA copy_to / restore,
+    reference base_experiment.py:630), which no version counter sees, can never leave stale operands behind."""
     from vit4hep_amd.trainer import CFMTrainer
 
     cfg = O.ds2(2)
@@ -143,20 +144,30 @@ def test_frozen_weight_operand_copies_are_reused_and_invalidated():
     t = torch.full((4, 1), 0.3, device=U.DEV)
     with torch.no_grad():
         a = model.forward(x, t, c)
-        params = [p.detach() for p in net.parameter_list()]
-        assert net.operands_current(params, net.inference_workspace(4, U.DEV), mark=False)  # second call will skip the casts
         b = model.forward(x, t, c)
-        assert torch.equal(a, b)
-        net.blocks[0].mlp.fc1.weight.mul_(1.5)  # torch in-place update bumps the version counter
-        assert not net.operands_current(params, net.inference_workspace(4, U.DEV), mark=False)
+        assert net._last_fwd_flags == 0 and torch.equal(a, b)  # no scope: recast, same result
+        w = net.blocks[0].mlp.fc1.weight
+        ver = w._version
+        w.data.copy_(w.data * 1.5)  # the EMA way: not tracked
+        assert w._version == ver
         d = model.forward(x, t, c)
-        assert not torch.equal(a, d)
+        assert net._last_fwd_flags == 0 and not torch.equal(a, d)
         fresh_fill = {k: v.clone() for k, v in fill.items()}
         fresh_fill["blocks.0.mlp.fc1.weight"] *= 1.5
         fresh = U.build_models(cfg, "bf16", fresh_fill).eval()
         assert torch.equal(d, fresh.forward(x, t, c))
-        # other batch size -> other workspace -> full refresh, still right
+        # other batch size -> other workspace -> still right
         assert torch.equal(model.forward(x[:2], t[:2], c[:2]), fresh.forward(x[:2], t[:2], c[:2]))
+        with net.frozen_weights():
+            e1 = model.forward(x, t, c)
+            assert net._last_fwd_flags == 0  # the first forward of a scope always recasts
+            e2 = model.forward(x, t, c)
+            assert net._last_fwd_flags == 2 | 4 and torch.equal(e1, e2) and torch.equal(e1, d)
+            net.blocks[0].mlp.fc1.weight.mul_(2.0)  # a tracked in-place update inside the scope is still noticed
+            e3 = model.forward(x, t, c)
+            assert net._last_fwd_flags == 0 and not torch.equal(e1, e3)
+        model.forward(x, t, c)
+        assert net._last_fwd_flags == 0  # scope left: back to recasting
     # the fused trainer rewrites parameters through raw pointers and bumps weights_epoch
     model.train()
     tr = CFMTrainer(model, iterations=10)
@@ -170,7 +181,7 @@ def test_frozen_weight_operand_copies_are_reused_and_invalidated():
 
 def test_condition_embedding_is_kept_across_evaluations_of_the_same_conditions():
     """V4H_FWD_SAME_CONDITION: the ODE solver evaluates the network many times for one condition tensor; the c_embedder term (independent
-    of t) is computed once.  Another tensor, an in-place write or changed weights recompute it."""
+    of t) is computed once.  Another tensor, an in-place write or changed weights recompute it.  (Inside a frozen_weights() scope only.)"""
     cfg = O.ds2(2)
     fill = O.golden_fill(cfg)
     for mode in ("f32", "bf16"):
@@ -179,7 +190,7 @@ def test_condition_embedding_is_kept_across_evaluations_of_the_same_conditions()
         x, c, _ = O.synthetic_batch(cfg, 4, 3)
         x, c = x.to(U.DEV), c.to(U.DEV)
         t1, t2 = torch.full((4, 1), 0.3, device=U.DEV), torch.full((4, 1), 0.7, device=U.DEV)
-        with torch.no_grad():
+        with torch.no_grad(), net.frozen_weights():
             model.forward(x, t1, c)
             assert net._last_fwd_flags == 0
             a = model.forward(x, t2, c)          # same conditions, other time

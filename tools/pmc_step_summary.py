@@ -1,12 +1,80 @@
-"""Sum FETCH_SIZE / WRITE_SIZE (KiB units) over all kernels of the profiled bench run; per step = total / (steps+warmup)."""
-import csv, glob, sys, collections
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_step.sh (bench.py itself under the profiler).
+
+  * FETCH_SIZE / WRITE_SIZE (KiB units) summed over every kernel of the run, per update step -> profiles/step_hbm_traffic.json, stamped with
+    the digest of the kernel sources (bench.py refuses a figure measured on other sources).  FETCH_SIZE is doubled: on gfx950 it reports half
+    the bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM).
+  * per kernel: MFMA-busy fraction of SQ busy cycles (a counter, not FLOP / time / peak), bf16 MFMA ops, LDS bank-conflict share, L2 hit rate,
+    device clock (GRBM_GUI_ACTIVE / duration) -> stdout (kept as profiles/<tag>_step_pmc_counters.md).
+usage: python tools/pmc_step_summary.py <steps incl. warmup> [tag]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 steps = int(sys.argv[1])
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"gpurun_out/pmc_step_{c}/**/*counter_collection.csv", recursive=True)
-    if not f: print(c, "missing"); continue
-    tot = 0.0; per = collections.Counter()
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+BASE = "gpurun_out/pmc_step"
+
+
+def short(k):
+    k = k.replace("void ", "")
+    for a, b in (("v4h_gemm_kernel<GemmCfg<", "gemm<"), ("(anonymous namespace)::", ""), ("v4h::", "")):
+        k = k.replace(a, b)
+    return k[:72]
+
+
+def load(name):
+    f = glob.glob(f"{BASE}/{name}/**/*counter_collection.csv", recursive=True)
+    per = collections.defaultdict(lambda: collections.Counter())
+    dur = collections.Counter()
+    calls = collections.Counter()
+    if not f:
+        return per, dur, calls
+    seen = set()
     for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] == c:
-            v = float(r["Counter_Value"]); tot += v; per[r["Kernel_Name"][:60]] += v
-    print(f"{c}: total {tot/1e6:.3f} GB(KiB-units*1e-6) over {steps} steps = {tot*1024/steps/1e9:.3f} GB/step (raw counter; FETCH_SIZE under-reports wide streaming reads by 2x on gfx950)")
-    for k, v in per.most_common(6): print(f"    {v*1024/steps/1e6:9.1f} MB/step  {k}")
+        k = short(r["Kernel_Name"])
+        per[r["Counter_Name"]][k] += float(r["Counter_Value"])
+        key = (r.get("Dispatch_Id"), r["Counter_Name"])
+        if r.get("Start_Timestamp") and (r.get("Dispatch_Id"), "t") not in seen:
+            seen.add((r.get("Dispatch_Id"), "t"))
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+            calls[k] += 1
+    return per, dur, calls
+
+
+fetch, _, _ = load("FETCH_SIZE")
+write, _, _ = load("WRITE_SIZE")
+tot_f = sum(fetch["FETCH_SIZE"].values()) * 1024 / steps
+tot_w = sum(write["WRITE_SIZE"].values()) * 1024 / steps
+print(f"HBM traffic per update step: FETCH_SIZE raw {tot_f/1e9:.3f} GB (x2 for 16-B/lane streams = {2*tot_f/1e9:.3f} GB), WRITE_SIZE {tot_w/1e9:.3f} GB  ->  {(2*tot_f+tot_w)/1e9:.3f} GB/step")
+if tot_f > 0 and tot_w > 0:
+    from vit4hep_amd.build import _digest
+
+    path = "profiles/step_hbm_traffic.json"
+    rec = json.load(open(path)) if os.path.exists(path) else {}
+    rec["ds2/bf16"] = {"bytes_per_step": 2 * tot_f + tot_w, "fetch_size_raw": tot_f, "write_size": tot_w, "kernel_digest": _digest(), "steps_profiled": steps,
+                       "how": "tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py; FETCH doubled per MI355X_MICROARCH.md"}
+    json.dump(rec, open(path, "w"), indent=1)
+    print(f"wrote {path}")
+
+mf, dur, calls = load("SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES")
+ops, _, _ = load("SQ_INSTS_VALU_MFMA_MOPS_BF16+SQ_WAVE_CYCLES")
+lds, _, _ = load("SQ_LDS_BANK_CONFLICT+SQ_LDS_IDX_ACTIVE")
+l2, _, _ = load("TCC_HIT_sum+TCC_MISS_sum")
+clk, cdur, _ = load("GRBM_GUI_ACTIVE")
+print(f"\nper kernel, {steps} steps (profiler build of the same run; durations under counter collection are longer than in a plain run)")
+print(f"{'kernel':72s} {'calls/step':>10s} {'us/call':>8s} {'MFMA busy %':>11s} {'bf16 MOPS/step':>14s} {'LDS confl %':>11s} {'L2 hit %':>8s} {'MB fetched/step':>15s} {'MB written/step':>15s} {'clock MHz':>9s}")
+keys = sorted(dur, key=lambda k: -dur[k])
+for k in keys[:28]:
+    busy = mf["SQ_BUSY_CYCLES"].get(k, 0.0)
+    mb = 100.0 * mf["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, 0.0) / busy if busy else float("nan")
+    la = lds["SQ_LDS_IDX_ACTIVE"].get(k, 0.0)
+    lc = 100.0 * lds["SQ_LDS_BANK_CONFLICT"].get(k, 0.0) / la if la else float("nan")
+    h, m = l2["TCC_HIT_sum"].get(k, 0.0), l2["TCC_MISS_sum"].get(k, 0.0)
+    hit = 100.0 * h / (h + m) if h + m else float("nan")
+    mhz = clk["GRBM_GUI_ACTIVE"].get(k, 0.0) / cdur[k] if cdur.get(k) else float("nan")
+    print(f"{k:72s} {calls[k]/steps:10.1f} {dur[k]/max(calls[k],1):8.1f} {mb:11.1f} {ops['SQ_INSTS_VALU_MFMA_MOPS_BF16'].get(k,0.0)/steps:14.3e} {lc:11.2f} {hit:8.1f} "
+          f"{2*fetch['FETCH_SIZE'].get(k,0.0)*1024/steps/1e6:15.1f} {write['WRITE_SIZE'].get(k,0.0)*1024/steps/1e6:15.1f} {mhz:9.0f}")

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -76,7 +76,7 @@ SIGNATURES = {
     "v4h_cfm_prepare": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
-    "v4h_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "v4h_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "v4h_axpby": (_i32, [_vp, _vp, _vp, _f32, _f32, _i64, _vp]),
     "v4h_rk4_combine": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "v4h_op_gemm": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -147,6 +147,13 @@ def check(rc, what=""):
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def on_device(t):
+    """Context: make the tensor's GPU the current device for the calls inside.  The library launches on torch's current stream OF THAT DEVICE and
+    creates a plan's side stream / events on the device that is current at its first call; with another device current (a model on cuda:1 without
+    torch.cuda.set_device) both would land on the wrong GPU."""
+    return torch.cuda.device(t.device)
 
 
 def stream_ptr(device=None):

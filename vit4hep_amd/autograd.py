@@ -9,10 +9,26 @@ import torch
 from . import _lib
 
 
+def _on_device_of(argpos):
+    """Decorator: run the wrapped call with the device of its tensor argument ``argpos`` current (see _lib.on_device)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*args, **kw):
+            with _lib.on_device(args[argpos]):
+                return fn(*args, **kw)
+
+        return wrapped
+
+    return deco
+
+
 def _vox_shape(net, B):
     return (B, 1, *net.voxel_shape())
 
 
+@_on_device_of(1)
 def _patchify(net, vox):
     plan = net._get_plan()
     B = vox.shape[0]
@@ -24,6 +40,7 @@ def _patchify(net, vox):
     return tok
 
 
+@_on_device_of(1)
 def _unpatchify(net, tok):
     plan = net._get_plan()
     B = tok.shape[0]
@@ -36,6 +53,7 @@ def _unpatchify(net, tok):
     return vox
 
 
+@_on_device_of(2)
 def run_forward(net, params, x_vox, t, c, training, ws=None):
     """Enqueue CaloChallengeCFM.forward on voxels.  Returns (out_vox, workspace)."""
     plan = net._get_plan()
@@ -67,6 +85,7 @@ def run_forward(net, params, x_vox, t, c, training, ws=None):
     return out, ws
 
 
+@_on_device_of(4)
 def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=None):
     plan = net._get_plan()
     B = dout_vox.shape[0] if dout_vox is not None else None
@@ -80,6 +99,7 @@ def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=Non
     )
 
 
+@_on_device_of(4)
 def run_backward_events(net, params, grads, dout_vox, ws, stage_events):
     """The whole backward pass as one library call; ``stage_events[s]`` (torch.cuda.Event, already created) is recorded as soon as the
     gradients of stage s are final (include/vit4hep_hip.h: v4h_vit_backward_events)."""

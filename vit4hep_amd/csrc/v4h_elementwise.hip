@@ -472,12 +472,16 @@ __global__ void sq_norm_kernel(const float* __restrict__ g, long n, float* __res
 // clip_grad_norm_ + torch.optim.AdamW single tensor (base_experiment.py:573-592; A12 of SURVEY.md):
 // coef = min(1, clip / (norm + 1e-6)); p *= 1 - lr wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                             const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2) {
+                             const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                             int* __restrict__ nonfinite) {
   float coef = 1.0f;
   if (gnorm_sq) {
     const float nrm = sqrtf(*gnorm_sq);
-    if (!isfinite(nrm)) return;  // error_if_nonfinite: leave the state untouched, the host raises (CFMTrainer.check_finite)
-    coef = fminf(1.0f, clip / (nrm + 1e-6f));
+    if (!isfinite(nrm)) {  // error_if_nonfinite (base_experiment.py:581): parameters and moments stay untouched, a sticky flag tells the host
+      if (nonfinite && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(nonfinite, 1);
+      return;
+    }
+    coef = fminf(1.0f, clip / (nrm + 1e-6f));  // clip = +inf (no clipping, the reference's max_norm = inf): 1
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
@@ -685,8 +689,8 @@ int sq_norm_accum(const float* g, long n, float* out, hipStream_t s) {
   return V4H_OK;
 }
 int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
-               float bc1, float bc2, hipStream_t s) {
-  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr, b1, b2, eps, wd, bc1, sqrtf(bc2));
+               float bc1, float bc2, int* nonfinite, hipStream_t s) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), nonfinite);
   V4H_CHECK_LAUNCH("adamw");
   return V4H_OK;
 }

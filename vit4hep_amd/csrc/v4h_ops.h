@@ -69,7 +69,7 @@ int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, flo
 int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s);
 int sq_norm_accum(const float* g, long n, float* out, hipStream_t s);  // out[0] += sum g^2 (atomic)
 int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
-               float bc1, float bc2, hipStream_t s);
+               float bc1, float bc2, int* nonfinite, hipStream_t s);
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
 int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
 

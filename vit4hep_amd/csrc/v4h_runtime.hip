@@ -57,12 +57,21 @@ struct v4h_plan {
   mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable int evi = 0;
   mutable bool side_ok = false;
+  mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
 };
 
 static bool g_overlap_wgrad = true;  // V4H_WGRAD_OVERLAP=0 disables the side stream
 static bool g_batch_adaln = true;    // V4H_BATCH_ADALN=0: per-block adaLN backward also in single-call passes (A/B hook)
 static int side_init(const v4h_plan& p) {
-  if (p.side_ok) return V4H_OK;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { v4h_set_error("hipGetDevice failed"); return V4H_ERR_HIP; }
+  if (p.side_ok) {
+    // the plan's side stream and events live on one device: a call made while another device is current would launch the weight gradients
+    // there (invalid-handle errors or cross-device accesses).  Bind a plan to one device; the Python host sets it around every call.
+    V4H_CHECK_ARG(dev == p.device, "plan is bound to device %d (its side stream and events) but device %d is current: set the device before the call, or use one plan per device", p.device, dev);
+    return V4H_OK;
+  }
+  p.device = dev;
   const char* e = getenv("V4H_WGRAD_OVERLAP");
   if (e && e[0] == '0') g_overlap_wgrad = false;
   e = getenv("V4H_BATCH_ADALN");
@@ -841,10 +850,10 @@ extern "C" int32_t v4h_sq_norm_accum(const float* g, int64_t n, float* out, void
   return sq_norm_accum(g, n, out, (hipStream_t)s);
 }
 extern "C" int32_t v4h_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr, float b1, float b2,
-                                  float eps, float wd, int32_t step, void* s) {
+                                  float eps, float wd, int32_t step, void* s, int32_t* nonfinite) {
   V4H_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adamw_step: bad argument");
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-  return adamw_step(p, g, m, v, n, gnorm_sq, max_norm, lr, b1, b2, eps, wd, (float)bc1, (float)bc2, (hipStream_t)s);
+  return adamw_step(p, g, m, v, n, gnorm_sq, max_norm, lr, b1, b2, eps, wd, (float)bc1, (float)bc2, nonfinite, (hipStream_t)s);
 }
 extern "C" int32_t v4h_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n, void* s) {
   V4H_CHECK_ARG(out && a && b && n > 0, "axpby: bad argument");

@@ -54,6 +54,11 @@ def fixed_grid(t0, t1, step):
 
 
 def _axpby(out, a, b, alpha, beta):
+    with _lib.on_device(out):
+        return _axpby_on(out, a, b, alpha, beta)
+
+
+def _axpby_on(out, a, b, alpha, beta):
     _lib.check(_lib.load().v4h_axpby(_lib.ptr(out), _lib.ptr(a), _lib.ptr(b), float(alpha), float(beta), out.numel(), _lib.stream_ptr(out.device)), "v4h_axpby")
     return out
 
@@ -92,8 +97,9 @@ def odeint_fixed(f, y0, t0, t1, method="rk4", step_size=0.05):
             _axpby(tmp, tmp, k2, 1.0, -dt)
             _axpby(tmp, tmp, k3, 1.0, dt)
             k4 = f(tb, tmp)
-            _lib.check(_lib.load().v4h_rk4_combine(_lib.ptr(y), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(k3), _lib.ptr(k4), float(dt), y.numel(),
-                                                   _lib.stream_ptr(y.device)), "v4h_rk4_combine")
+            with _lib.on_device(y):
+                _lib.check(_lib.load().v4h_rk4_combine(_lib.ptr(y), _lib.ptr(k1), _lib.ptr(k2), _lib.ptr(k3), _lib.ptr(k4), float(dt), y.numel(),
+                                                       _lib.stream_ptr(y.device)), "v4h_rk4_combine")
     return y
 
 
@@ -148,6 +154,12 @@ class CFM(BaseModel):
             t_vec = torch.full((B, 1), float(t), dtype=x_T.dtype, device=x_T.device)
             return self.forward(x_t, t_vec, batch)
 
+        core = self.net
+        while hasattr(core, "module"):  # DDP(model.net) of the reference (base_experiment.py:161-167)
+            core = core.module
+        if hasattr(core, "frozen_weights"):  # the solver's evaluations share frozen weights and one condition batch
+            with core.frozen_weights():
+                return odeint_fixed(f, x_T, 0.0, 1.0, method, float(step))
         return odeint_fixed(f, x_T, 0.0, 1.0, method, float(step))
 
     @torch.inference_mode()

@@ -29,7 +29,10 @@ def _aligned(n, a=64):
 
 
 class CFMTrainer:
-    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None):
+    NONFINITE_MSG = "The total norm for gradients is non-finite, so it cannot be clipped."  # torch.nn.utils.clip_grad_norm_'s own text
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None,
+                 nonfinite_check_every=50):
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
 
         self.model = model
@@ -42,6 +45,10 @@ class CFMTrainer:
         self.iterations = int(iterations)
         self.step_count = 0
         self.group = group
+        # The reference raises on a non-finite gradient norm BEFORE optimizer.step(), also without clipping (max_norm = inf; base_experiment.py:573-585).
+        # Here the update kernel skips such a step on the device and bumps a sticky counter; the host looks at it every `nonfinite_check_every`
+        # steps (one 4-byte read) and in check_finite(), raises the same error and rewinds step_count / the LR schedule by the skipped updates.
+        self.nonfinite_check_every = int(nonfinite_check_every)
         self._flatten()
 
     # ---------------------------------------------------------------------------------------------- flat buffers
@@ -81,6 +88,7 @@ class CFMTrainer:
         self.stage_events = None
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
 
     def _check_alias(self):
         if any(p.data_ptr() != v.data_ptr() for p, v in ((self.params[0], self.p_views[0]), (self.params[-1], self.p_views[-1]))):
@@ -97,6 +105,10 @@ class CFMTrainer:
     def loss_and_grads(self, x, c, t=None, x0=None):
         """Forward + backward into the flat gradient buffer (all-reduced over the data-parallel group)."""
         self._check_alias()
+        with _lib.on_device(self.flat_p):
+            return self._loss_and_grads(x, c, t, x0)
+
+    def _loss_and_grads(self, x, c, t, x0):
         lib = _lib.load()
         dev = self.flat_p.device
         x = _lib.require_cuda(x, "x")
@@ -137,6 +149,10 @@ class CFMTrainer:
 
     def step(self, x, c, t=None, x0=None):
         """One BaseExperiment._step.  Returns (loss, grad_norm) as 0-dim device tensors (pre-clip norm, like clip_grad_norm_)."""
+        with _lib.on_device(self.flat_p):
+            return self._step(x, c, t, x0)
+
+    def _step(self, x, c, t, x0):
         lib = _lib.load()
         loss = self.loss_and_grads(x, c, t, x0)
         s = _lib.stream_ptr(self.flat_p.device)
@@ -146,8 +162,8 @@ class CFMTrainer:
         lr = self.lr_at(self.step_count - 1)
         _lib.check(
             lib.v4h_adamw_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
-                               _lib.ptr(self.gnorm_sq) if self.clip is not None else None, self.clip or 0.0, lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                               self.step_count, s),
+                               _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                               self.step_count, s, _lib.ptr(self.nonfinite)),
             "v4h_adamw_step",
         )
         self.net.weights_epoch += 1  # parameters rewritten through raw pointers: invalidate cached operand copies (ViT.operands_current)
@@ -155,12 +171,23 @@ class CFMTrainer:
         if collectives_enabled():
             dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
             out_loss /= world()
+        if self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
+            self.raise_if_nonfinite()
         return out_loss, self.gnorm_sq.sqrt()
+
+    def raise_if_nonfinite(self):
+        """Host look at the sticky device counter of skipped (non-finite) updates: raise like the reference, with step_count and the LR schedule
+        rewound to the last update that was applied."""
+        skipped = int(self.nonfinite.item())
+        if skipped:
+            self.nonfinite.zero_()
+            self.step_count -= skipped
+            raise RuntimeError(f"{self.NONFINITE_MSG} ({skipped} update(s) skipped on the device; step_count rewound to {self.step_count})")
 
     @staticmethod
     def check_finite(grad_norm):
         """error_if_nonfinite=True of the reference's clip_grad_norm_ call (base_experiment.py:581); needs a host sync."""
         g = float(grad_norm)
         if not math.isfinite(g):
-            raise RuntimeError("The total norm for gradients is non-finite, so it cannot be clipped.")
+            raise RuntimeError(CFMTrainer.NONFINITE_MSG)
         return g
