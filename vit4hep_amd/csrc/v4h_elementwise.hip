@@ -415,6 +415,174 @@ template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_boun
   }
 }
 
+// ---- wide forms (D % 8 == 0): a lane owns 8 CONSECUTIVE columns (c = 8 lane + 512 n), so every 16-bit tensor is touched with 16-byte and every
+// f32 tensor with 2 x 16-byte accesses per lane - the 4-column forms above read and write bf16 in 8-byte pieces, which run at 0.5-0.7 of the
+// 16-byte rate (MI355X_MICROARCH.md).  D = 480: 60 of 64 lanes active, one group per lane.
+template <typename T, int NV8> __global__ __launch_bounds__(256) void ln_modulate_fwd8_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                                                  const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
+                                                                                  float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;
+  const int b = row / Tn;
+  const float* xr = x + (long)row * D;
+  f32x8 v[NV8];
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[n].v[r] = 0.f;
+    if (c < D) {
+      v[n] = load8(xr + c);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += v[n].v[r];
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+    if (c < D) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float d = v[n].v[r] - mu;
+        q += d * d;
+      }
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-6f);
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+    if (c < D) {
+      const f32x8 sh = load8(shift + (long)b * ld_mod + c), sc = load8(scale + (long)b * ld_mod + c);
+      f32x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o.v[r] = (v[n].v[r] - mu) * rs * (1.0f + sc.v[r]) + sh.v[r];
+      store8(u + (long)row * D + c, o);
+    }
+  }
+}
+
+template <typename T, int NV8, int LNB_ROWS, int R> __global__ __launch_bounds__(256) void ln_modulate_bwd8_kernel(const LnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * LNB_ROWS;
+  const int t1 = min(a.T, t0 + LNB_ROWS);
+  const int D = a.D;
+  const T* du = reinterpret_cast<const T*>(a.du);
+  const T* y = reinterpret_cast<const T*>(a.y);
+  f32x8 acc_sh[NV8], acc_sc[NV8], acc_g[NV8], sc[NV8], gt[NV8];
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc_sh[n].v[r] = acc_sc[n].v[r] = acc_g[n].v[r] = sc[n].v[r] = gt[n].v[r] = 0.f;
+    if (c < D) {
+      sc[n] = load8(a.scale + (long)b * a.ld_mod + c);
+      if (y) gt[n] = load8(a.gate + (long)b * a.ld_mod_gate + c);
+    }
+  }
+  for (int tb = t0 + wave * R; tb < t1; tb += 4 * R) {
+    long row[R];
+    bool ok[R];
+    float mu[R], rs[R], s1[R], s2[R];
+    f32x8 gy[R][NV8], xh[R][NV8], dxi[R][NV8], yv[R][NV8];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      ok[q] = tb + q < t1;
+      row[q] = (long)b * a.T + (ok[q] ? tb + q : t0);
+      mu[q] = a.mean[row[q]];
+      rs[q] = a.rstd[row[q]];
+      s1[q] = s2[q] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const int c = lane * 8 + 512 * n;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) gy[q][n].v[r] = xh[q][n].v[r] = dxi[q][n].v[r] = yv[q][n].v[r] = 0.f;
+        if (c < D && ok[q]) {
+          gy[q][n] = load8(du + row[q] * D + c);   // holds du for now
+          xh[q][n] = load8(a.x + row[q] * D + c);  // holds x for now
+          if (a.dx_in) dxi[q][n] = load8(a.dx_in + row[q] * D + c);
+          if (y) yv[q][n] = load8(y + row[q] * D + c);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const int c = lane * 8 + 512 * n;
+        if (c < D && ok[q]) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float d = gy[q][n].v[r];
+            const float xhat = (xh[q][n].v[r] - mu[q]) * rs[q];
+            xh[q][n].v[r] = xhat;
+            gy[q][n].v[r] = d * (1.0f + sc[n].v[r]);
+            acc_sh[n].v[r] += d;
+            acc_sc[n].v[r] += d * xhat;
+            s1[q] += gy[q][n].v[r];
+            s2[q] += gy[q][n].v[r] * xhat;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      s1[q] = wave_sum(s1[q]) / (float)D;
+      s2[q] = wave_sum(s2[q]) / (float)D;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const int c = lane * 8 + 512 * n;
+        if (c < D && ok[q]) {
+          f32x8 dx, dyv;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            dx.v[r] = rs[q] * (gy[q][n].v[r] - s1[q] - xh[q][n].v[r] * s2[q]) + dxi[q][n].v[r];
+            acc_g[n].v[r] += dx.v[r] * yv[q][n].v[r];
+            dyv.v[r] = dx.v[r] * gt[n].v[r];
+          }
+          if (a.dx_out) store8(a.dx_out + row[q] * D + c, dx);
+          if (a.dx_out_t) store8(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
+          if (y) store8(reinterpret_cast<T*>(a.dy) + row[q] * D + c, dyv);
+        }
+      }
+    }
+  }
+  // cross-wave reduction through LDS, then one atomic per feature
+  __shared__ float red[3][4][NV8 * 512];
+#pragma unroll
+  for (int n = 0; n < NV8; ++n)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int c = lane * 8 + 512 * n + r;
+      red[0][wave][c] = acc_sh[n].v[r];
+      red[1][wave][c] = acc_sc[n].v[r];
+      red[2][wave][c] = acc_g[n].v[r];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float v0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float v1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(a.dshift + (long)b * a.ld_dmod + c, v0);
+    atomicAdd(a.dscale + (long)b * a.ld_dmod + c, v1);
+    if (y) {
+      const float v2 = red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c];
+      atomicAdd(a.dgate + (long)b * a.ld_dgate + c, v2);
+    }
+  }
+}
+
 template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pre, T* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (T)(ds[i] * dsilu_f(pre[i]));
@@ -636,7 +804,14 @@ int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* sca
                     hipStream_t s) {
   V4H_CHECK_ARG(D % 4 == 0 && D <= 1024, "ln_modulate: hidden_dim %d unsupported (multiple of 4, <= 1024)", D);
   const dim3 grid((BT + 3) / 4);
-  if (D <= 512) {
+  static const bool wide = !(getenv("V4H_LN_WIDE") && getenv("V4H_LN_WIDE")[0] == '0');  // A/B hook
+  const bool al = ((uintptr_t)x % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ld_mod % 4 == 0;
+  if (wide && al && D % 8 == 0) {
+#define V4H_LNF8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D)
+    if (D <= 512) { if (m == MODE_BF16) V4H_LNF8(bf16, 1); else V4H_LNF8(float, 1); }
+    else { if (m == MODE_BF16) V4H_LNF8(bf16, 2); else V4H_LNF8(float, 2); }
+#undef V4H_LNF8
+  } else if (D <= 512) {
     if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
     else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
   } else {
@@ -650,7 +825,15 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 1024, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
   // 16 rows per workgroup, 2 rows in flight per wave: measured best (4 rows in flight or 32-48 rows per workgroup: -1...-6 % end to end)
 #define V4H_LNB_LAUNCH(TT, MAXV) hipLaunchKernelGGL((ln_modulate_bwd_kernel<TT, MAXV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
-  if (a.D <= 512) {
+#define V4H_LNB8_LAUNCH(TT, NV) hipLaunchKernelGGL((ln_modulate_bwd8_kernel<TT, NV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
+  static const bool wide = !(getenv("V4H_LN_WIDE") && getenv("V4H_LN_WIDE")[0] == '0');  // A/B hook
+  auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  const bool al = al16(a.du) && al16(a.x) && al16(a.dx_in) && al16(a.dx_out) && al16(a.dx_out_t) && al16(a.y) && al16(a.dy) && al16(a.scale) && al16(a.gate) &&
+                  a.ld_mod % 4 == 0 && a.ld_mod_gate % 4 == 0;
+  if (wide && al && a.D % 8 == 0) {
+    if (a.D <= 512) { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 1); else V4H_LNB8_LAUNCH(float, 1); }
+    else { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 2); else V4H_LNB8_LAUNCH(float, 2); }
+  } else if (a.D <= 512) {
     if (m == MODE_BF16) V4H_LNB_LAUNCH(bf16, 2);
     else V4H_LNB_LAUNCH(float, 2);
   } else {
@@ -658,6 +841,7 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
     else V4H_LNB_LAUNCH(float, 4);
   }
 #undef V4H_LNB_LAUNCH
+#undef V4H_LNB8_LAUNCH
   V4H_CHECK_LAUNCH("ln_modulate_bwd");
   return V4H_OK;
 }
