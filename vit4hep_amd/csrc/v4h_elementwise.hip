@@ -418,9 +418,13 @@ template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_boun
 // ---- wide forms (D % 8 == 0): a lane owns 8 CONSECUTIVE columns (c = 8 lane + 512 n), so every 16-bit tensor is touched with 16-byte and every
 // f32 tensor with 2 x 16-byte accesses per lane - the 4-column forms above read and write bf16 in 8-byte pieces, which run at 0.5-0.7 of the
 // 16-byte rate (MI355X_MICROARCH.md).  D = 480: 60 of 64 lanes active, one group per lane.
+// With `y` given the kernel first applies the gated residual update of the branch above (nn/vit.py:331-332): x = x + gate[b] * y, written to
+// x_out - the contraction that produced y then has a plain-store epilogue instead of reading and rewriting the f32 residual stream.
 template <typename T, int NV8> __global__ __launch_bounds__(256) void ln_modulate_fwd8_kernel(const float* __restrict__ x, const float* __restrict__ shift,
                                                                                   const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
-                                                                                  float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D) {
+                                                                                  float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D,
+                                                                                  const T* __restrict__ y, const float* __restrict__ gate, int ld_gate,
+                                                                                  float* __restrict__ x_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
@@ -435,6 +439,12 @@ template <typename T, int NV8> __global__ __launch_bounds__(256) void ln_modulat
     for (int r = 0; r < 8; ++r) v[n].v[r] = 0.f;
     if (c < D) {
       v[n] = load8(xr + c);
+      if (y) {
+        const f32x8 yv = load8(y + (long)row * D + c), gv = load8(gate + (long)b * ld_gate + c);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[n].v[r] += gv.v[r] * yv.v[r];
+        store8(x_out + (long)row * D + c, v[n]);
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) s += v[n].v[r];
     }
@@ -807,7 +817,7 @@ int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* sca
   static const bool wide = !(getenv("V4H_LN_WIDE") && getenv("V4H_LN_WIDE")[0] == '0');  // A/B hook
   const bool al = ((uintptr_t)x % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ld_mod % 4 == 0;
   if (wide && al && D % 8 == 0) {
-#define V4H_LNF8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D)
+#define V4H_LNF8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)nullptr, (const float*)nullptr, 0, (float*)nullptr)
     if (D <= 512) { if (m == MODE_BF16) V4H_LNF8(bf16, 1); else V4H_LNF8(float, 1); }
     else { if (m == MODE_BF16) V4H_LNF8(bf16, 2); else V4H_LNF8(float, 2); }
 #undef V4H_LNF8
@@ -819,6 +829,22 @@ int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* sca
     else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 4>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
   }
   V4H_CHECK_LAUNCH("ln_modulate_fwd");
+  return V4H_OK;
+}
+bool ln_resid_supported(int D) { return D % 8 == 0 && D <= 1024; }
+// x_out = x + gate[b] * y, then LayerNorm + modulate of x_out (the wide kernel only: D % 8 == 0, 16-byte aligned tensors)
+int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* gate, int ld_gate, float* x_out, const float* shift, const float* scale, int ld_mod,
+                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  V4H_CHECK_ARG(ln_resid_supported(D) && y && gate && x_out, "ln_resid_modulate: hidden_dim %d unsupported or null tensor", D);
+  V4H_CHECK_ARG(al16(x) && al16(y) && al16(gate) && al16(x_out) && al16(shift) && al16(scale) && al16(u) && ld_gate % 4 == 0 && ld_mod % 4 == 0,
+                "ln_resid_modulate: tensors must be 16-byte aligned");
+  const dim3 grid((BT + 3) / 4);
+#define V4H_LNR8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
+  if (D <= 512) { if (m == MODE_BF16) V4H_LNR8(bf16, 1); else V4H_LNR8(float, 1); }
+  else { if (m == MODE_BF16) V4H_LNR8(bf16, 2); else V4H_LNR8(float, 2); }
+#undef V4H_LNR8
+  V4H_CHECK_LAUNCH("ln_resid_modulate_fwd");
   return V4H_OK;
 }
 int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {

@@ -42,6 +42,10 @@ int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t 
 
 int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
                     hipStream_t s);
+bool ln_resid_supported(int D);
+// x_out = x + gate[b] * y (gated residual of the branch above, nn/vit.py:331-332), then LayerNorm + modulate of x_out
+int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* gate, int ld_gate, float* x_out, const float* shift, const float* scale, int ld_mod,
+                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s);
 struct LnBwdArgs {
   // LayerNorm+modulate backward (reference nn/vit.py:309-311,331-332,457-458)
   const void* du;       // [BT][D] mode type: grad wrt the modulated output
