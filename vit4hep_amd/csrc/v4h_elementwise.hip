@@ -67,6 +67,40 @@ template <typename T> __global__ void patchify_kernel(const float* __restrict__ 
   const int Tn = g.l * g.a * g.r;
   xp[((long)b * Tn + n) * Ppad + f] = (T)vox[idx];
 }
+// The same through LDS, as a regular grid allows: the p1 voxel layers that make up one row of patches are ONE contiguous block of the input
+// (p1 * A * R floats of sample b, starting at layer li * p1).  A workgroup reads its block of (layer, eta, phi) voxels with coalesced 16-byte
+// loads into LDS and writes the a * r token rows of that block, each lane 8 consecutive features of a token (16 bytes of bf16), zero padding
+// included - so neither side of the transpose touches HBM with a stride.
+template <typename T> __global__ __launch_bounds__(256) void patchify_slab_kernel(const float* __restrict__ vox, T* __restrict__ xp, PatchGeom g, int P, int Ppad) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int li = blockIdx.x, b = blockIdx.y;
+  const int S = g.p1 * g.A * g.R;
+  const float* src = vox + ((long)b * g.L + (long)li * g.p1) * g.A * g.R;
+  if ((S & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+    for (int k = threadIdx.x; k < S / 4; k += blockDim.x) reinterpret_cast<f32x4*>(slab)[k] = reinterpret_cast<const f32x4*>(src)[k];
+  } else {
+    for (int k = threadIdx.x; k < S; k += blockDim.x) slab[k] = src[k];
+  }
+  __syncthreads();
+  const int ntok = g.a * g.r, Tn = g.l * ntok, cpr = Ppad / 8;  // 8-feature chunks per token row
+  T* dst = xp + ((long)b * Tn + (long)li * ntok) * Ppad;
+  for (int e = threadIdx.x; e < ntok * cpr; e += blockDim.x) {
+    const int tok = e / cpr, f0 = (e % cpr) * 8;
+    const int ai = tok / g.r, ri = tok % g.r;
+    f32x8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int f = f0 + k;
+      float val = 0.f;
+      if (f < P) {
+        const int pk = f % g.p3, pj = (f / g.p3) % g.p2, pi = f / (g.p3 * g.p2);
+        val = slab[(pi * g.A + ai * g.p2 + pj) * g.R + ri * g.p3 + pk];
+      }
+      v.v[k] = val;
+    }
+    store8(dst + (long)tok * Ppad + f0, v);
+  }
+}
 template <typename T> __global__ void zero_pad_cols_kernel(T* __restrict__ xp, long rows, int P, int Ppad) {
   const int w = Ppad - P;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -736,6 +770,14 @@ int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_
   return V4H_OK;
 }
 int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s) {
+  const size_t slab_bytes = (size_t)g.p1 * g.A * g.R * 4;
+  static const bool staged = !(getenv("V4H_PATCHIFY_LDS") && getenv("V4H_PATCHIFY_LDS")[0] == '0');
+  if (staged && Ppad % 8 == 0 && slab_bytes <= 48 * 1024 && ((uintptr_t)xp % 16) == 0 && B <= 65535) {  // regular grid through LDS (one launch, padding included)
+    if (m == MODE_BF16) hipLaunchKernelGGL(patchify_slab_kernel<bf16>, dim3(g.l, B), dim3(256), slab_bytes, s, vox, (bf16*)xp, g, P, Ppad);
+    else hipLaunchKernelGGL(patchify_slab_kernel<float>, dim3(g.l, B), dim3(256), slab_bytes, s, vox, (float*)xp, g, P, Ppad);
+    V4H_CHECK_LAUNCH("patchify/slab");
+    return V4H_OK;
+  }
   const long n = (long)B * g.L * g.A * g.R;
   const long rows = (long)B * g.l * g.a * g.r;
   const int nb = (int)((n + 255) / 256);

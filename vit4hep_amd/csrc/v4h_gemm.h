@@ -113,6 +113,30 @@ V4H_DEV f32x8 add8(f32x8 a, const f32x8& b) {
   return a;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// two accumulator tiles a, b (lane (c, g) holds columns 4g..4g+3 of row c) -> lanes with even g hold columns 8(g>>1)..+7 of
+// tile a, lanes with odd g the same columns of tile b (v_permlane16_swap: odd 16-lane rows of the first operand <-> even
+// rows of the second).
+// (inline assembly: the __builtin_amdgcn_permlane16_swap of this ROCm folds the four swaps of a tile pair into one - wrong code;
+// the two wait states a VALU write of either operand needs before the swap reads it are not padded inside asm, hence the s_nop)
+V4H_DEV f32x8 swap_pair(f32x4 a, f32x4 b) {
+  f32x8 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = a[r], y = b[r];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    o.v[r] = x;
+    o.v[4 + r] = y;
+  }
+  return o;
+}
+V4H_DEV u32x4 pack_bf16x8(const f32x8& x) {
+  bf16x8 o;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = (bf16)x.v[r];
+  return __builtin_bit_cast(u32x4, o);
+}
+
 // Epilogue on 8 consecutive columns j..j+7 of row i (j % 8 == 0, J % 8 == 0 checked by the launcher), in two halves so
 // that the kernel can issue EVERY load of a strip before its first store: s_waitcnt vmcnt counts loads and stores in one
 // in-order queue, so a load waited for after a store would drain that store's whole round trip.

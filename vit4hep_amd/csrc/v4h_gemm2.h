@@ -19,7 +19,6 @@
 #pragma once
 #include "v4h_gemm.h"
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // Fragment addressing with a minimum of registers.  The images are the dense swizzled ones of v4h_gemm.h; what is new is that a wave keeps only
 // the byte offsets that really differ per lane (2 to 4 integers per operand) and reaches every other fragment through the instruction's
@@ -99,28 +98,6 @@ V4H_DEV void wait_vmcnt64(int n) {
 #undef V4H_VM_CASE
 }
 
-// two accumulator tiles a, b (lane (c, g) holds columns 4g..4g+3 of row c) -> lanes with even g hold columns 8(g>>1)..+7 of
-// tile a, lanes with odd g the same columns of tile b (v_permlane16_swap: odd 16-lane rows of the first operand <-> even
-// rows of the second).
-// (inline assembly: the __builtin_amdgcn_permlane16_swap of this ROCm folds the four swaps of a tile pair into one - wrong code;
-// the two wait states a VALU write of either operand needs before the swap reads it are not padded inside asm, hence the s_nop)
-V4H_DEV f32x8 swap_pair(f32x4 a, f32x4 b) {
-  f32x8 o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x = a[r], y = b[r];
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    o.v[r] = x;
-    o.v[4 + r] = y;
-  }
-  return o;
-}
-V4H_DEV u32x4 pack_bf16x8(const f32x8& x) {
-  bf16x8 o;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) o[r] = (bf16)x.v[r];
-  return __builtin_bit_cast(u32x4, o);
-}
 
 template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
