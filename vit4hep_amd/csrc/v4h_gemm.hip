@@ -161,7 +161,10 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   *nz_out = (a.K + klen - 1) / klen;
   if (m == MODE_BF16 && g_v2 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
     return v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
-  if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 160, 96, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
+  // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the
+  // split the runtime uses); 96 x 160 is 2-4 % ahead on three of the four block shapes
+  if (m == MODE_BF16 && g_cfg_wgrad == 12) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 160, 96, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab160x96");
+  if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 96, 160, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
   return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
 }
 

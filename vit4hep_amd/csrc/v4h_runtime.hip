@@ -421,7 +421,7 @@ static GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int
 // K splits of a wgrad: a multiple of 8 (one or more per XCD) giving about one workgroup per CU; every split costs one
 // f32-atomic pass over the output (~1.3 TB/s chip-wide), so no more than that.
 static int wgrad_splitk(int I, int J, int K) {
-  const int tiles = ((I + 159) / 160) * ((J + 95) / 96);
+  const int tiles = ((I + 95) / 96) * ((J + 159) / 160);  // 96 x 160 tiles (v4h_gemm.hip: gemm_wgrad_slab)
   int sk = tiles >= 40 ? 8 : 16;
   if (tiles < 8) sk = 32;
   const int maxk = K / 128;  // at least 4 K-steps per split
