@@ -19,7 +19,24 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 BASE = "gpurun_out/pmc_step"
 
 
+def _short_gemm(n):
+    import re
+    m = re.match(r"_Z15v4h_gemm_kernelI7GemmCfgI(DF16b|f)(DF16b|f)Lb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)ELb(\d)", n)
+    if m:
+        t, _, pks, qks, bi, bj, bk, epi, cs = m.groups()
+        epis = ["STORE", "STORE_F32", "SILU", "COND_SUM", "EMBED", "GATE_RESID", "GELU", "DGELU", "DSILU", "ATOMIC_F32", "ACCUM_F32", "UNPATCH", "SLAB_F32", "RELU", "ROWADD_SILU"]
+        lay = {("0", "0"): "fwd", ("0", "1"): "dgrad", ("1", "1"): "wgrad"}[(pks, qks)]
+        return f"gemm<{'bf16' if t == 'DF16b' else 'f32'},{lay},{bi}x{bj}x{bk},{epis[int(epi)]}{',colsum' if cs == '1' else ''}>"
+    m = re.match(r"_ZN(?:3v4h)?12_GLOBAL__N_1(\d+)([A-Za-z_0-9]+)", n)
+    if m:
+        return m.group(2)[:int(m.group(1))]
+    return None
+
+
 def short(k):
+    g = _short_gemm(k)
+    if g:
+        return g
     k = k.replace("void ", "")
     for a, b in (("v4h_gemm_kernel<GemmCfg<", "gemm<"), ("(anonymous namespace)::", ""), ("v4h::", "")):
         k = k.replace(a, b)
@@ -66,15 +83,18 @@ lds, _, _ = load("SQ_LDS_BANK_CONFLICT+SQ_LDS_IDX_ACTIVE")
 l2, _, _ = load("TCC_HIT_sum+TCC_MISS_sum")
 clk, cdur, _ = load("GRBM_GUI_ACTIVE")
 print(f"\nper kernel, {steps} steps (profiler build of the same run; durations under counter collection are longer than in a plain run)")
+NSIMD = 1024  # 256 CUs x 4
+print("MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x kernel duration x 2.4 GHz): the share of the peak-clock cycle budget in which "
+      "a SIMD's matrix pipe was busy - a counter, comparable with FLOP / time / peak; the chip clocks BELOW 2.4 GHz under this load (last column: GRBM_GUI_ACTIVE / 8 / "
+      "duration, which reads high on dispatches shorter than ~0.3 ms - MI355X_MICROARCH.md, DVFS).")
 print(f"{'kernel':72s} {'calls/step':>10s} {'us/call':>8s} {'MFMA busy %':>11s} {'bf16 MOPS/step':>14s} {'LDS confl %':>11s} {'L2 hit %':>8s} {'MB fetched/step':>15s} {'MB written/step':>15s} {'clock MHz':>9s}")
 keys = sorted(dur, key=lambda k: -dur[k])
 for k in keys[:28]:
-    busy = mf["SQ_BUSY_CYCLES"].get(k, 0.0)
-    mb = 100.0 * mf["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, 0.0) / busy if busy else float("nan")
+    mb = 100.0 * mf["SQ_VALU_MFMA_BUSY_CYCLES"].get(k, 0.0) / (NSIMD * dur[k] * 2400.0) if dur.get(k) else float("nan")
     la = lds["SQ_LDS_IDX_ACTIVE"].get(k, 0.0)
     lc = 100.0 * lds["SQ_LDS_BANK_CONFLICT"].get(k, 0.0) / la if la else float("nan")
     h, m = l2["TCC_HIT_sum"].get(k, 0.0), l2["TCC_MISS_sum"].get(k, 0.0)
     hit = 100.0 * h / (h + m) if h + m else float("nan")
-    mhz = clk["GRBM_GUI_ACTIVE"].get(k, 0.0) / cdur[k] if cdur.get(k) else float("nan")
+    mhz = clk["GRBM_GUI_ACTIVE"].get(k, 0.0) / 8.0 / cdur[k] if cdur.get(k) else float("nan")
     print(f"{k:72s} {calls[k]/steps:10.1f} {dur[k]/max(calls[k],1):8.1f} {mb:11.1f} {ops['SQ_INSTS_VALU_MFMA_MOPS_BF16'].get(k,0.0)/steps:14.3e} {lc:11.2f} {hit:8.1f} "
           f"{2*fetch['FETCH_SIZE'].get(k,0.0)*1024/steps/1e6:15.1f} {write['WRITE_SIZE'].get(k,0.0)*1024/steps/1e6:15.1f} {mhz:9.0f}")
