@@ -687,6 +687,81 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
       for (int y = 0; y < C::TJ; ++y) sum += acc[x][y];
     const int i = i0 + wi * C::WTI + c, j = j0 + wj * C::WTJ + 4 * g;
     if (i < a.I && j < a.J) store4(reinterpret_cast<typename C::TO*>(a.e.out) + (size_t)i * a.e.ldo + j, sum);
+  } else if constexpr ((C::EPI == EPI_STORE || C::EPI == EPI_GELU || C::EPI == EPI_DGELU) && sizeof(T) == 2 && sizeof(typename C::TO) == 2 && C::TJ % 2 == 1 &&
+                       C::TI % 2 == 0 && C::DBG != 9) {
+    // bf16 outputs straight from the registers: pairs of 16 x 16 accumulator tiles are exchanged between the 16-lane groups (v_permlane16_swap,
+    // swap_pair), after which a lane holds 8 consecutive columns of a row = 16-byte accesses for the output and for every element-wise operand;
+    // no LDS strip, no LDS wait between the last MFMA and the first store.  Column-tile pairs (y, y + 1) give 64 contiguous bytes per row and
+    // instruction; the odd last column tile is paired over two row strips.  Measured against the LDS-strip epilogue below on the eight
+    // plain-store shapes of a block: 6-9 % less time per call (tools/gemm_bench.py cfg 29 = DBG 9 = strips; profiles/r02_gemm_direct_store.txt).
+    using TO = typename C::TO;
+    constexpr int NCH = C::TI * C::TJ / 2;
+    const int ge = g & 1, gh = g >> 1;
+    const int rowA = i0 + wi * C::WTI + c, colA = j0 + wj * C::WTJ + 16 * ge + 8 * gh;
+    const int colT = j0 + wj * C::WTJ + (C::TJ - 1) * 16 + 8 * gh;
+    auto pos = [&](int n, int& i, int& j) {  // chunk n of this lane: row, first column
+      constexpr int NP = C::TJ / 2;          // column-tile pairs per row strip
+      if (n < C::TI * NP) { i = rowA + (n / NP) * 16; j = colA + (n % NP) * 32; }
+      else { i = rowA + (2 * (n - C::TI * NP) + ge) * 16; j = colT; }
+    };
+    auto val = [&](int n) -> f32x8 {
+      constexpr int NP = C::TJ / 2;
+      if (n < C::TI * NP) return swap_pair(acc[n / NP][2 * (n % NP)], acc[n / NP][2 * (n % NP) + 1]);
+      return swap_pair(acc[2 * (n - C::TI * NP)][C::TJ - 1], acc[2 * (n - C::TI * NP) + 1][C::TJ - 1]);
+    };
+    if constexpr (C::EPI == EPI_DGELU) {  // out = acc * aux: the saved gelu' of the whole wave tile is requested up front (NCH x 4 VGPRs of raw bf16)
+      bf16x8 raw[NCH];
+      const TO* aux = reinterpret_cast<const TO*>(a.e.aux);
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        int i, j;
+        pos(n, i, j);
+        if (i < a.I && j + 8 <= a.J) raw[n] = *reinterpret_cast<const bf16x8*>(aux + (size_t)i * a.e.ld_aux + j);
+      }
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        int i, j;
+        pos(n, i, j);
+        f32x8 v = val(n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v.v[r] *= (float)raw[n][r];
+        if (i < a.I && j + 8 <= a.J) store8(reinterpret_cast<TO*>(a.e.out) + (size_t)i * a.e.ldo + j, v);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NCH; ++n) {
+        int i, j;
+        pos(n, i, j);
+        f32x8 v = val(n);
+        const bool ok = i < a.I && j + 8 <= a.J;
+        if (a.e.bias != nullptr && j + 8 <= a.J) v = add8(v, load8(a.e.bias + j));
+        if constexpr (C::EPI == EPI_STORE) {
+          if (ok) store8(reinterpret_cast<TO*>(a.e.out) + (size_t)i * a.e.ldo + j, v);
+        } else {  // EPI_GELU: out = gelu'(pre) (training only), out2 = gelu(pre)
+          if (a.e.out) {
+            f32x8 d;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+            if (ok) store8(reinterpret_cast<TO*>(a.e.out) + (size_t)i * a.e.ldo + j, d);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v.v[r] = gelu_only<T>(v.v[r]);
+          }
+          if (ok) store8(reinterpret_cast<TO*>(a.e.out2) + (size_t)i * a.e.ldo2 + j, v);
+        }
+      }
+    }
+  } else if constexpr (C::EPI == EPI_SLAB_F32 && sizeof(T) == 2 && C::DBG != 9) {
+    // f32 split-K partials straight from the registers: a lane's 4 accumulator registers are 4 consecutive columns = one 16-byte store, 64
+    // contiguous bytes per row and instruction; no exchange needed
+    float* slab = reinterpret_cast<float*>(a.e.out) + (size_t)tz * a.e.slab_stride;
+#pragma unroll
+    for (int x = 0; x < C::TI; ++x)
+#pragma unroll
+      for (int y = 0; y < C::TJ; ++y) {
+        const int i = i0 + wi * C::WTI + x * 16 + c, j = j0 + wj * C::WTJ + y * 16 + 4 * g;
+        if (i < a.I && j + 4 <= a.J) store4(slab + (size_t)i * a.e.ldo + j, acc[x][y]);
+      }
   } else if constexpr (C::DBG != 3) {
     // Every other epilogue: the MFMA accumulator layout (a lane holds 4 columns of ONE row, 16 rows per instruction) makes
     // 8-byte stores into 16 different cache lines.  Instead each wave passes its tile through a private LDS strip, 16 rows

@@ -30,11 +30,18 @@ inline bool big_fwd(const GemmArgs& a) { return g_big && a.I >= 4096 && (a.J % 1
 inline bool big_dgrad(const GemmArgs& a) { return g_big && a.I >= 4096 && a.J % 192 == 0 && a.J >= 960; }
 
 // ---- tile-shape tuning hook (tools/gemm_bench.py): selects the configuration used for EPI_STORE fwd/dgrad and wgrad ----
-int g_cfg = 0, g_cfg_wgrad = 0, g_stagger = 0;
+int g_cfg = env_flag("V4H_GEMM_CFG", 0), g_cfg_wgrad = env_flag("V4H_GEMM_WCFG", 0), g_stagger = 0;  // (env: A/B runs of whole steps)
+// Which epilogues go through the LDS strips (default: all) instead of straight from the registers (bit 0 plain store, 1 GELU, 2 DGELU, 3 split-K slab).
+// The register form (v_permlane16_swap pairs, 16-byte stores, 64-byte row segments) wins 6-9 % per call when the SAME buffers are re-used in a
+// loop (tools/gemm_bench.py: outputs stay cache-resident) and LOSES inside the update step (201.6 vs 209.9 steps/s with all four on it; GELU with
+// its two outputs 84.8 vs 69.1 us per call): cold output lines written in 64-byte pieces cost more than whole-row strips.  Kept as a measured
+// negative result and as the A/B hook that found it (profiles/r02_gemm_direct_store.txt).
+int g_strips = env_flag("V4H_GEMM_STRIPS", 15);
 template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_t s, const char* name) {
   GemmArgs a = a0;
   a.stagger_sleeps = g_stagger;
   if constexpr (sizeof(T) == 2) {
+    if (g_cfg == 0 && (g_strips & 1)) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 9>>(a, 1, s, name);
     if (g_cfg == 0 && g_ring) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false, 0, 4>>(a, 1, s, name);
     if (g_cfg == 20) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false>>(a, 1, s, name);
     if (g_cfg == 21) return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 32, 2, 2, EPI_STORE, false, 4, 4>>(a, 1, s, name);
@@ -51,6 +58,7 @@ template <typename T, bool QKS> int run_store_cfg(const GemmArgs& a0, hipStream_
       case 19: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 3, EPI_STORE, false>>(a, 1, s, name);
       case 22: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 256, 192, 64, 4, 2, EPI_STORE, false>>(a, 1, s, name);
       case 28: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 7>>(a, 1, s, name);
+      case 29: return v4h_gemm_launch<GemmCfg<T, T, false, QKS, 128, 160, 64, 2, 2, EPI_STORE, false, 9>>(a, 1, s, name);  // LDS-strip epilogue (A/B of the register store)
       // (measured and removed: 112-row tiles - 465 instead of 405 tiles on the 512 slots for J = 480 - as 1 x 5 or 1 x 2 waves: 13-35 % slower)
       // (measured and removed: one 8-wave workgroup per CU with a 4-deep ring of BK = 64 slabs, 108 KB in flight: 25-40 % slower
       //  than two 4-wave workgroups with two slabs each - DESIGN.md section 5)
@@ -113,6 +121,7 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if constexpr (sizeof(T) == 2) { if (big_fwd(a)) return run_big<T, T, false, EPI_GATE_RESID>(a, s, "gemm_fwd/gate_resid/big"); }
       return run<T, T, false, false, 128, 160, EPI_GATE_RESID>(a, 1, s, "gemm_fwd/gate_resid");
     case EPI_GELU:
+      if constexpr (sizeof(T) == 2) { if (g_cfg == 29 || (g_strips & 2)) return v4h_gemm_launch<GemmCfg<T, T, false, false, 128, 160, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu/strips"); }
       if constexpr (sizeof(T) == 2) { if (big_fwd(a)) return run_big<T, T, false, EPI_GELU>(a, s, "gemm_fwd/gelu/big"); }
       return run<T, T, false, false, 128, 160, EPI_GELU>(a, 1, s, "gemm_fwd/gelu");
     case EPI_UNPATCH: return run<T, T, false, false, 128, 96, EPI_UNPATCH>(a, 1, s, "gemm_fwd/unpatch");
@@ -133,6 +142,7 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
   switch (epi) {
     case EPI_STORE: return run_store_cfg<T, true>(a, s, "gemm_dgrad/store");
     case EPI_DGELU:
+      if constexpr (sizeof(T) == 2) { if (g_cfg == 29 || (g_strips & 4)) return v4h_gemm_launch<GemmCfg<T, T, false, true, 128, 160, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu/strips"); }
       if constexpr (sizeof(T) == 2) { if (big_dgrad(a)) return run_big<T, T, true, EPI_DGELU>(a, s, "gemm_dgrad/dgelu/big"); }
       return run<T, T, false, true, 128, 160, EPI_DGELU>(a, 1, s, "gemm_dgrad/dgelu");
     case EPI_DSILU: return run<T, T, false, true, 128, 160, EPI_DSILU>(a, 1, s, "gemm_dgrad/dsilu");
@@ -163,6 +173,7 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
     return v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the
   // split the runtime uses); 96 x 160 is 2-4 % ahead on three of the four block shapes
+  if (m == MODE_BF16 && (g_cfg_wgrad == 13 || (g_strips & 8))) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 96, 160, 64, 2, 2, EPI_SLAB_F32, true, 9>>(a, splitk, s, "gemm_wgrad/slab/strips");
   if (m == MODE_BF16 && g_cfg_wgrad == 12) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 160, 96, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab160x96");
   if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 96, 160, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
   return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
