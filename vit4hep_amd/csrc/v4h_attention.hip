@@ -194,6 +194,11 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 // Single-chunk case (T <= 160, i.e. ds2): a persistent workgroup walks (batch, head) items id, id + grid, ... and DMAs the NEXT
 // item's K and V (global_load_lds, dense 160-byte rows, rows >= T from the zero page) into the other LDS buffer while it
 // computes the current one, so the load -> compute serialisation of the one-shot kernel disappears.  One barrier per item.
+// (Round 2 built two more forms of this kernel and measured them inside the step: Q through the DMA as well + counted vmcnt waits + buffer stores
+// - no store drain at the barrier - 21.8 -> 21.8 us per call; that plus a third of the vector instructions removed - K = 16 MFMA for the head_dim
+// tail instead of masked K = 32 slabs, base-2 softmax with the scale folded in, DMA offsets computed once - 21.6 -> 20.0 us.  Neither the store
+// drain nor the instruction count is what bounds it; both forms were dropped again.  What the kernel moves per call is 66 MB in 160-byte row
+// slices of 2880-byte rows: 3.0 TB/s.)
 template <typename T, int DH> struct AttnDense {
   static constexpr int CPRD = DH * (int)sizeof(T) / 16;        // 16-byte chunks per row
   static constexpr int UNITS = KC * CPRD, NI = (UNITS + 63) / 64;
@@ -319,123 +324,6 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 }
 
 
-// Second form of the persistent forward (bf16, T <= 160): NO vector-memory instruction returns data to registers.  Q travels through the
-// LDS DMA like K and V (three images per buffer, six in all = 150 KB), the results leave through buffer stores whose bounds check replaces the
-// row predicate, and the top-of-item wait is a COUNTED `s_waitcnt vmcnt(stores of the previous item)` + raw `s_barrier`: the previous form's
-// __syncthreads drained the memory counter, i.e. waited once per item for its own output stores' round trip (the dominant cost of the 24 us
-// kernel: three items per workgroup, each ending in a store drain).
-template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void attn_fwd_persist2_kernel(const T* __restrict__ qkv, T* __restrict__ o,
-                                                                                                      float* __restrict__ lse, int Tn, int H, int nitems,
-                                                                                                      float scale, int Btot) {
-  using C = AttnCfg<T, DH>;
-  using DI = AttnDense<T, DH>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [Q0 | K0 | V0 | Q1 | K1 | V1]
-  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = H * DH, ld = 3 * D;
-  const int ntiles = (Tn + 15) / 16;
-  const bool active = wave < ntiles;
-  auto stage_item = [&](int it, int buf) {
-    const T* base = qkv + (size_t)(it / H) * Tn * ld + (it % H) * DH;
-    char* img = smem + buf * 3 * DI::BYTES;
-    DI::stage(img, base, ld, Tn, wave, NW, lane);
-    DI::stage(img + DI::BYTES, base + D, ld, Tn, wave, NW, lane);
-    DI::stage(img + 2 * DI::BYTES, base + 2 * D, ld, Tn, wave, NW, lane);
-  };
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(o, 0, (int)min((long)Btot * Tn * D * 2, 0x7FFFFFF0L), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(lse, 0, lse ? (int)min((long)Btot * H * Tn * 4, 0x7FFFFFF0L) : 0, 0x00020000);
-  constexpr unsigned OOB = 0x7FFFFFF0u;
-  constexpr int NSTORE = C::NDT / 2 + (C::NDT & 1) + 1;  // vector-memory instructions an active wave issues per item after the DMA requests
-  const int Bn = nitems / H;
-  int it = attn_item(blockIdx.x, gridDim.x, 0, Bn, H);
-  if (it >= 0) stage_item(it, 0);
-  bool stored = false;  // this wave's stores of the previous item are younger than the DMA of the current one
-  for (int n = 0; it >= 0; ++n) {
-    const int buf = n & 1;
-    const int it_next = attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H);
-    // this item's images have landed: everything older than the (at most NSTORE) stores of the previous item is complete
-    if (stored) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    asm volatile("s_barrier" ::: "memory");
-    if (it_next >= 0) stage_item(it_next, buf ^ 1);
-    stored = false;
-    if (active) {
-      const T* sQ = reinterpret_cast<const T*>(smem + buf * 3 * DI::BYTES);
-      const T* sK = reinterpret_cast<const T*>(smem + buf * 3 * DI::BYTES + DI::BYTES);
-      const T* sV = reinterpret_cast<const T*>(smem + buf * 3 * DI::BYTES + 2 * DI::BYTES);
-      const int b = it / H, h = it % H;
-      Frag<T> xq[C::NKF];
-#pragma unroll
-      for (int s2 = 0; s2 < C::NKF; ++s2) {
-        xq[s2] = frag_kcontig(sQ, DH, wave * 16, 32 * s2, lane);
-        if (32 * s2 + 8 * g + 8 > DH) xq[s2] = frag_zero<T>();
-      }
-      f32x4 p[C::NJT];
-      float mx = -INFINITY;
-#pragma unroll
-      for (int jt = 0; jt < C::NJT; ++jt) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s2 = 0; s2 < C::NKF; ++s2) {
-          Frag<T> kf = frag_kcontig(sK, DH, jt * 16, 32 * s2, lane);
-          if (32 * s2 + 8 * g + 8 > DH) kf = frag_zero<T>();
-          a = mma(kf, xq[s2], a);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = jt * 16 + 4 * g + r;
-          a[r] = key < Tn ? a[r] * scale : -INFINITY;
-          mx = fmaxf(mx, a[r]);
-        }
-        p[jt] = a;
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float rs = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < C::NJT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[jt][r] = __expf(p[jt][r] - mx);
-          rs += p[jt][r];
-        }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      f32x4 oacc[C::NDT];
-#pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < C::NJT / 2; ++ks) {
-        const Frag<T> wf = frag_from_acc(p[2 * ks], p[2 * ks + 1], T());
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = mma(frag_kstrided2(sV, DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
-      }
-      const int q = wave * 16 + c;
-      const float inv = 1.0f / rs;
-      const unsigned rowoff = (unsigned)(((size_t)b * Tn + q) * D + h * DH) * 2u;  // byte offset of the lane's output row (same row for every g)
-      const bool ok = q < Tn;
-      const int ge = g & 1, gh = g >> 1;
-#pragma unroll
-      for (int d = 0; d + 1 < C::NDT; d += 2) {
-        f32x8 v = swap_pair(oacc[d], oacc[d + 1]);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v.v[r] *= inv;
-        __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro, ok ? rowoff + (unsigned)((d + ge) * 16 + 8 * gh) * 2u : OOB, 0, 0);
-      }
-      if constexpr (C::NDT & 1) {
-        bf16x4 t4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t4[r] = (bf16)(oacc[C::NDT - 1][r] * inv);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, t4), ro,
-                                              ok ? rowoff + (unsigned)((C::NDT - 1) * 16 + 4 * g) * 2u : OOB, 0, 0);
-      }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mx + __logf(rs)), rl, (ok && g == 0) ? (unsigned)(((size_t)b * H + h) * Tn + q) * 4u : OOB, 0, 0);
-      stored = true;
-    }
-    it = it_next;
-  }
-}
 
 // ------------------------------------------------------------------------------------------------- backward
 // dQ: lane side = queries, streamed = keys (K and V chunks in LDS)
@@ -811,16 +699,6 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
   const int ntiles = (Tn + 15) / 16;
   if constexpr (sizeof(T) == 2) {
     static const bool persist = !(getenv("V4H_ATTN_PERSIST") && getenv("V4H_ATTN_PERSIST")[0] == '0');
-    static const bool persist2 = !(getenv("V4H_ATTN_FWD2") && getenv("V4H_ATTN_FWD2")[0] == '0');  // A/B hook
-    if (persist && persist2 && Tn <= KC && ntiles <= 9 && (long)B * Tn * H * DH * 2 < 0x7FFFFFF0L) {  // Q, K, V through the DMA, counted waits, buffer stores
-      constexpr int NW = 9;
-      const size_t lds = 6 * (size_t)AttnDense<T, 80>::BYTES + 64;
-      int rc = set_lds(attn_fwd_persist2_kernel<T, 80, NW>, lds, "attn_fwd_persist2");
-      if (rc) return rc;
-      hipLaunchKernelGGL((attn_fwd_persist2_kernel<T, 80, NW>), dim3(256), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, B * H, 1.0f / sqrtf((float)DH), B);
-      V4H_CHECK_LAUNCH("attn_fwd_persist2");
-      return V4H_OK;
-    }
     if (persist && Tn <= KC && ntiles <= 9) {  // single key chunk: persistent, double-buffered K/V
       constexpr int NW = 9;
       const size_t lds = 4 * (size_t)AttnDense<T, 80>::BYTES + 64;
