@@ -211,7 +211,7 @@ def test_wgrad_slab_operator_exact(kernel):
             assert torch.equal(out, P.float().t() @ Q.float() + 1.0)  # accumulates into the gradient tensor
             assert torch.equal(cs, P.float().sum(0))
     finally:
-        lib.v4h_debug_set_gemm_cfg(0, 1000)
+        lib.v4h_debug_set_gemm_cfg(0, -1)
 
 
 @pytest.mark.parametrize("qks", [0, 1])
@@ -230,7 +230,7 @@ def test_ring_kernel_forward_and_dgrad_exact(qks):
             # integer operands: the f32 accumulation is exact, the only rounding is the final one to bf16
             assert torch.equal(out.float(), want.to(torch.bfloat16).float()), (I, J, K)
     finally:
-        lib.v4h_debug_set_gemm_cfg(0, 1000)
+        lib.v4h_debug_set_gemm_cfg(0, -1)
 
 
 # ---------------------------------------------------------------------------------------------------------------- hipGraph capture
@@ -262,3 +262,21 @@ def test_inference_forward_can_be_captured_into_a_graph():
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(got, model.forward(x2, t, c))
+
+
+def test_sampling_batch_256_uses_the_ring_kernel_and_matches():
+    """At the reference's sampling batch of 256 the token count (34560) is a whole number of 256-row tiles and the forward contractions take the
+    256 x 160 ring kernel (v4h_gemm2.h) by default; rows must agree with a small batch (two-workgroup kernel) and with the oracle."""
+    cfg = O.ds2(6)
+    fill = O.golden_fill(cfg)
+    model = U.build_models(cfg, "bf16", fill).eval()
+    x, c, g = O.synthetic_batch(cfg, 256, 77)
+    t, x0 = O.synthetic_noise(cfg, 256, g)
+    xt = ((1 - t) * x0 + t * x).to(U.DEV)
+    t, c = t.view(-1, 1).to(U.DEV), c.to(U.DEV)
+    with torch.no_grad():
+        full = model.forward(xt, t, c)
+        part = model.forward(xt[100:104].contiguous(), t[100:104].contiguous(), c[100:104].contiguous())
+    assert U.rel_err(full[100:104], part) < 1e-2
+    ref = O.cfm_forward(fill, xt[101:102].cpu(), t[101:102].cpu(), c[101:102].cpu(), cfg)
+    assert U.rel_err(full[101:102], ref) < 3e-2

@@ -95,4 +95,4 @@ for nm, I, J, K, pks, qks, sk in shapes:
     m1, m2 = t1[len(t1) // 2], t2[len(t2) // 2]
     print(f"{nm:16s} I={I:6d} J={J:5d} K={K:6d} split={sk:2d} | old {m1:7.1f} us {fl/m1/1e6:7.1f} TF (min {t1[0]:6.1f}) err {res[1][0]:.1e} | new {m2:7.1f} us {fl/m2/1e6:7.1f} TF "
           f"(min {t2[0]:6.1f}) err {res[2][0]:.1e} | x{m1/m2:.3f}" + "".join(f" | abl{v} {sorted(res[v][1:])[len(res[v][1:]) // 2]:6.1f} us" for v in abl), flush=True)
-lib.v4h_debug_set_gemm_cfg(0, 0)
+lib.v4h_debug_set_gemm_cfg(0, -1)

@@ -40,4 +40,4 @@ for nm, I, J in (("wgrad qkv", 3 * D, D), ("wgrad proj", D, D), ("wgrad fc1", M,
                 ts.append(timeit(fn))
             res.append(f"{name} {sorted(ts)[1]:6.1f} us ({2.0*I*J*BT/sorted(ts)[1]/1e6:5.0f} TF, err {err:.0e})")
         print(f"{nm:11s} split {sk:2d} | " + " | ".join(res), flush=True)
-lib.v4h_debug_set_gemm_cfg(0, 1000)
+lib.v4h_debug_set_gemm_cfg(0, -1)

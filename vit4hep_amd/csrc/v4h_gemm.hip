@@ -93,14 +93,19 @@ template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream
 }
 
 // ---- 256 x 160 / 8-wave / three-stage kernel (v4h_gemm2.h): bf16, token-sized contractions ----
-int g_v2 = env_flag("V4H_GEMM2", 0);  // off by default: measured slower than the two-workgroup kernel on 7 of 8 block shapes (profiles/r02_gemm2_ablation.md)
-inline bool v2_ok(const GemmArgs& a, int klen) {
-  return g_v2 && a.I >= 2048 && a.J % 160 == 0 && klen >= 192 && a.e.ldo % 8 == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 4 < 0x7FFFFFF0L;
+// V4H_GEMM2: -1 (default) = where it was measured to win INSIDE the path: forward contractions whose token count is a whole number of 256-row tiles
+// (the sampler at the reference's batch of 256: 34560 rows = 135 tiles; 1210 -> 1270 showers/s, profiles/r02_ab_in_context.txt); 0 = never;
+// 1 = wherever eligible (the update step at bs = 128, 67.5 row tiles: 195 vs 208 steps/s - not the default); 2.. = ablation builds (tools/gemm2_bench.py).
+int g_v2 = env_flag("V4H_GEMM2", -1);
+inline bool v2_eligible(const GemmArgs& a, int klen) {
+  return a.I >= 2048 && a.J % 160 == 0 && klen >= 192 && a.e.ldo % 8 == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 4 < 0x7FFFFFF0L;
 }
+inline bool v2_ok(const GemmArgs& a, int klen) { return g_v2 > 0 && v2_eligible(a, klen); }
+inline bool v2_auto_fwd(const GemmArgs& a) { return g_v2 < 0 && a.I % 256 == 0 && a.I >= 8192 && v2_eligible(a, a.K); }
 
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (v2_ok(a, a.K)) {
+    if (v2_ok(a, a.K) || v2_auto_fwd(a)) {
       if (epi == EPI_STORE && g_v2 == 2) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1>>(a, 1, s, "gemm2_fwd/store/dbg1");
       if (epi == EPI_STORE && g_v2 == 3) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2>>(a, 1, s, "gemm2_fwd/store/dbg2");
       if (epi == EPI_STORE && g_v2 == 4) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 3>>(a, 1, s, "gemm2_fwd/store/dbg3");
@@ -169,7 +174,7 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + bk - 1) / bk * bk;
   *nz_out = (a.K + klen - 1) / klen;
-  if (m == MODE_BF16 && g_v2 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
+  if (m == MODE_BF16 && g_v2 > 0 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
     return v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the
   // split the runtime uses); 96 x 160 is 2-4 % ahead on three of the four block shapes
@@ -180,6 +185,7 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
 }
 
 void debug_set_gemm_cfg(int cfg, int cfg_wgrad) {
+  if (cfg_wgrad < 0) { g_v2 = -1; cfg_wgrad = 0; }  // back to the default choice
   if (cfg_wgrad >= 1000) { g_v2 = cfg_wgrad / 1000 - 1; cfg_wgrad %= 1000; }
   g_cfg = cfg % 100; g_stagger = cfg / 100; g_cfg_wgrad = cfg_wgrad % 100; g_big = cfg_wgrad / 100 ? 0 : 1; }
 
