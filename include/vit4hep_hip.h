@@ -10,7 +10,7 @@
  * every v4h_vit_forward / v4h_vit_backward* call, so calls on one plan must be serialised by the caller (one host thread per plan,
  * or a lock); distinct plans may be used from distinct threads once each contraction variant has been launched at least once (the
  * first launch of a variant sets its dynamic-LDS attribute without a lock) - warm up on one thread.  v4h_last_error() is
- * per process, not per thread.  A plan binds to the device that is current at its first forward / backward call (side stream and
+ * thread-local (the message of the calling thread's last failed call).  A plan binds to the device that is current at its first forward / backward call (side stream and
  * events live there); later calls with another device current are rejected.  Environment switches (V4H_*) are read once.
  *
  * The reference has no native boundary of its own (pure Python): each entry point below replaces
