@@ -39,7 +39,7 @@ TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profile
 
 def measured_traffic(workload, mode):
     try:
-        from vit4hep_amd.build import _digest
+        from vit4hep_amd.build import kernel_digest as _digest
 
         with open(TRAFFIC_FILE) as fh:
             rec = json.load(fh)

@@ -68,7 +68,7 @@ tot_f = sum(fetch["FETCH_SIZE"].values()) * 1024 / steps
 tot_w = sum(write["WRITE_SIZE"].values()) * 1024 / steps
 print(f"HBM traffic per update step: FETCH_SIZE raw {tot_f/1e9:.3f} GB (x2 for 16-B/lane streams = {2*tot_f/1e9:.3f} GB), WRITE_SIZE {tot_w/1e9:.3f} GB  ->  {(2*tot_f+tot_w)/1e9:.3f} GB/step")
 if tot_f > 0 and tot_w > 0:
-    from vit4hep_amd.build import _digest
+    from vit4hep_amd.build import kernel_digest as _digest
 
     path = "profiles/step_hbm_traffic.json"
     rec = json.load(open(path)) if os.path.exists(path) else {}

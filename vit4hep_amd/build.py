@@ -37,6 +37,18 @@ def _digest():
     return h.hexdigest()
 
 
+def kernel_digest():
+    """Digest of what determines the device code: every file under csrc/ and the compiler flags (not the C header's comments).  profiles/step_hbm_traffic.json is
+    stamped with it, and bench.py reports a measured `traffic` only for the build it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def _compile(src, report):
     out = os.path.join(OBJ, src.replace(".hip", ".o"))
     cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", out]
