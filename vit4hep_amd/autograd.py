@@ -16,7 +16,10 @@ def _on_device_of(argpos):
     def deco(fn):
         @functools.wraps(fn)
         def wrapped(*args, **kw):
-            with _lib.on_device(args[argpos]):
+            ref = args[argpos] if len(args) > argpos else next((v for v in list(args) + list(kw.values()) if isinstance(v, torch.Tensor) and v.is_cuda), None)
+            if not (isinstance(ref, torch.Tensor) and ref.is_cuda):  # no device tensor to go by: the call itself raises the proper error
+                return fn(*args, **kw)
+            with _lib.on_device(ref):
                 return fn(*args, **kw)
 
         return wrapped
