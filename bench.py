@@ -168,6 +168,12 @@ def op_rates(mode, BT, device, reps=20):
     return out
 
 
+# V4H_BENCH_REHEARSAL=1: rehearse the N-rank path on a box with ONE GPU - every rank computes on cuda:0 and the collectives go over gloo (RCCL refuses two ranks on
+# one device).  Exercises the launcher, the rendezvous, the bucketed all-reduce behind the library's stage events and the max-over-ranks timing; its numbers mean
+# nothing (N ranks share one card) and the JSON line says "rehearsal": true.
+REHEARSAL = os.environ.get("V4H_BENCH_REHEARSAL") == "1"
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one process per GPU, RCCL over xGMI) the way the reference's main.py:9-26
     spawns its own, as CHILD processes of a parent that never touches the GPU, pass rank 0's JSON line through and return the children's code."""
@@ -175,7 +181,7 @@ def launch_ranks(n):
     import subprocess
 
     have = torch.cuda.device_count()  # (counting devices does not initialise the runtime)
-    if have < n:
+    if have < n and not REHEARSAL:
         print(f"bench.py: --gpus {n} but only {have} GPU(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -295,6 +301,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    if REHEARSAL:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     import torch.distributed as dist
@@ -305,7 +313,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", init_method="env://", device_id=torch.device(device))
+        if REHEARSAL:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=torch.device(device))
 
     from vit4hep_amd.trainer import CFMTrainer
 
@@ -375,6 +386,8 @@ def main():
         }
         if traffic_note:
             rec["roofline"]["traffic_note"] = traffic_note
+        if REHEARSAL:
+            rec["rehearsal"] = True  # N ranks on one GPU over gloo: a functional check of the multi-rank path, not a measurement
         if world == 1 and not args.no_op_rates:
             rec["gemm_ops"] = op_rates(args.mode, B * T, device)
         if world == 1 and not args.no_sampling and args.workload == "ds2":

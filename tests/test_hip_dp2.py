@@ -1,0 +1,114 @@
+"""-m gpu: the HIP trainer with world_size 2.  The build boxes have ONE MI355X and RCCL refuses two ranks on one device, so the two ranks share cuda:0 and the
+collectives go over gloo (CUDA tensors staged through the host): everything except the transport is the production path - CFMTrainer with the whole backward as one
+library call, a stage event per backward stage recorded by the library, each stage's contiguous gradient slice all-reduced on the communication stream behind its
+event, 1/world folded into the loss-gradient seed, the loss averaged over ranks (reference experiments/base_experiment.py:161-167, 600-601).
+
+Each rank trains on its half of a batch; the trajectory must equal a single process training on the whole batch (gradient of the global-batch mean loss)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, mode, steps, out):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    import torch.distributed as dist
+
+    from oracle import vit_cfm_oracle as O
+    from tests import hiputil as U
+    from vit4hep_amd.parallel import collectives_enabled, shard_rows
+    from vit4hep_amd.trainer import CFMTrainer
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = O.ds2(2)
+        B = 8
+        x, c, g = O.synthetic_batch(cfg, B, 17)
+        noise = [O.synthetic_noise(cfg, B, g) for _ in range(steps)]
+        lo, hi = shard_rows(B, rank, world)
+        model = U.build_models(cfg, mode, O.golden_fill(cfg))
+        tr = CFMTrainer(model, iterations=20)
+        assert collectives_enabled()
+        losses, norms = [], []
+        for t, x0 in noise:
+            l, n = tr.step(x[lo:hi].to(U.DEV), c[lo:hi].to(U.DEV), t[lo:hi].to(U.DEV), x0[lo:hi].to(U.DEV))
+            losses.append(float(l))
+            norms.append(float(n))
+        sd = model.state_dict()
+        out[rank] = (losses, norms, {k: sd[k].cpu().numpy() for k in ("net.blocks.0.attn.qkv.weight", "net.final_layer.linear.bias", "net.pos_embed_freqs")})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_two_rank_hip_trainer_matches_single_process_on_the_whole_batch(mode):
+    import torch.multiprocessing as mp
+
+    from oracle import vit_cfm_oracle as O
+    from tests import hiputil as U
+    from vit4hep_amd.trainer import CFMTrainer
+
+    steps = 3
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, mode, steps, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    out = dict(out)
+    # single process, whole batch
+    cfg = O.ds2(2)
+    x, c, g = O.synthetic_batch(cfg, 8, 17)
+    noise = [O.synthetic_noise(cfg, 8, g) for _ in range(steps)]
+    model = U.build_models(cfg, mode, O.golden_fill(cfg))
+    tr = CFMTrainer(model, iterations=20)
+    ref_l, ref_n = [], []
+    for t, x0 in noise:
+        l, n = tr.step(x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV))
+        ref_l.append(float(l))
+        ref_n.append(float(n))
+    sd = model.state_dict()
+    tol = 1e-5 if mode == "f32" else 2e-3
+    for r in (0, 1):
+        losses, norms, w = out[r]
+        assert np.allclose(losses, ref_l, rtol=tol), (r, losses, ref_l)   # the loss is averaged over the ranks
+        assert np.allclose(norms, ref_n, rtol=10 * tol), (r, norms, ref_n)  # norm of the all-reduced gradient
+        for k, v in w.items():
+            assert U.rel_err(torch.from_numpy(v), sd[k]) < (1e-4 if mode == "f32" else 5e-3), (r, k)
+    for k in out[0][2]:  # and both ranks hold the same weights
+        assert np.array_equal(out[0][2][k], out[1][2][k]) or U.rel_err(torch.from_numpy(out[0][2][k]), torch.from_numpy(out[1][2][k])) < 1e-6, k
+
+
+def test_bench_gpus_2_launches_its_ranks_rehearsal():
+    """`python bench.py --gpus 2` end to end on the one-GPU box (V4H_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo transport): the parent spawns the ranks through
+    torch.distributed.run before touching the GPU, rank 0's JSON line comes back with n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["V4H_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "ds2_d2"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert rec["n_gpus"] == 2 and rec["rehearsal"] is True and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 16
+    assert np.isfinite(rec["loss"]) and rec["value"] > 0
