@@ -165,6 +165,26 @@ def op_rates(mode, BT, device, reps=20):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         out[name] = {"us": round(us, 2), "tflops": round(2.0 * BT * J * K / us / 1e6, 1)}
+    # the dominant kernel of the step: the split-K weight gradients (dW = dY^T X over the tokens; partial slabs + ordered reduce, bias-gradient column sums on)
+    for name, (I, J) in {"wgrad qkv 1440x480": (1440, 480), "wgrad proj 480x480": (480, 480), "wgrad fc1 1920x480": (1920, 480), "wgrad fc2 480x1920": (480, 1920)}.items():
+        sk = 8 if I * J >= 40 * 96 * 160 else 16
+        P = torch.randn((BT, I), device=device).to(dt)
+        Q = torch.randn((BT, J), device=device).to(dt)
+        o = torch.zeros((I, J), device=device)
+        slab = torch.empty((sk, I, J), device=device)
+        cs = torch.zeros(I, device=device)
+        s = _lib.stream_ptr(device)
+        args = (_lib.MODES[mode], _lib.ptr(P), I, _lib.ptr(Q), J, _lib.ptr(slab), _lib.ptr(o), I, J, BT, sk, _lib.ptr(cs), s)
+        for _ in range(3):
+            _lib.check(lib.v4h_op_gemm_wgrad_slab(*args))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            _lib.check(lib.v4h_op_gemm_wgrad_slab(*args))
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        out[name] = {"us": round(us, 2), "tflops": round(2.0 * BT * I * J / us / 1e6, 1), "splitk": sk}
     return out
 
 
