@@ -18,6 +18,25 @@
 
 #include "v4h_ops.h"
 
+#ifdef V4H_ATTN_STAMPS
+// Diagnostic build only (V4H_EXTRA_FLAGS=-DV4H_ATTN_STAMPS): wave 0 of every workgroup stamps the constant 100 MHz clock at the phase boundaries of each item
+// into a buffer no kernel reads; v4h_debug_attn_stamps copies it out (tools/experiments/attn_stamps.py).
+__device__ unsigned long long v4h_attn_stamps[256 * 4 * 8];
+__device__ unsigned long long v4h_attn_arrive[256 * 4 * 16];  // [workgroup][item][wave]: arrival at the top-of-item barrier
+#define V4H_STAMP(n, k)                                                                                        \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && (n) < 4) v4h_attn_stamps[(blockIdx.x * 4 + (n)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+extern "C" int v4h_debug_attn_arrivals(void* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(v4h_attn_arrive), sizeof(v4h_attn_arrive)) == hipSuccess ? 0 : 1;
+}
+extern "C" int v4h_debug_attn_stamps(void* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(v4h_attn_stamps), sizeof(v4h_attn_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define V4H_STAMP(n, k) do {} while (0)
+#endif
+
 namespace {
 
 // Row store of NDT 16-column accumulator tiles (lane (c, g): row c, columns 16 dt + 4g .. + 3): pairs of tiles are exchanged between the
@@ -199,12 +218,27 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 // tail instead of masked K = 32 slabs, base-2 softmax with the scale folded in, DMA offsets computed once - 21.6 -> 20.0 us.  Neither the store
 // drain nor the instruction count is what bounds it; both forms were dropped again.  What the kernel moves per call is 66 MB in 160-byte row
 // slices of 2880-byte rows: 3.0 TB/s.)
+V4H_DEV bool dma_duty_balanced() {
+#ifdef V4H_ATTN_DMA_ALL_WAVES
+  return false;
+#else
+  return true;
+#endif
+}
 template <typename T, int DH> struct AttnDense {
   static constexpr int CPRD = DH * (int)sizeof(T) / 16;        // 16-byte chunks per row
   static constexpr int UNITS = KC * CPRD, NI = (UNITS + 63) / 64;
   static constexpr int BYTES = NI * 1024;                       // whole DMA instructions
   // stage rows [0, KC) x DH of a token-major tensor (row stride ld elements) into a dense image
+  // `wave` of `nw`: which DMA instructions this wave issues.  With nine waves (3 + 2 + 2 + 2 on the four SIMDs) the three waves of SIMD 0 set the pace of an item
+  // (profiles/r02_attn_fwd_timeline.txt), so the DMA duty (about 1 us per wave and item: address arithmetic + 60-185 cycles of issue per piece) is given to the six
+  // waves of the other SIMDs only.
   static V4H_DEV void stage(char* img, const T* base, int ld, int rows_end, int wave, int nw, int lane) {
+    if (nw == 9 && dma_duty_balanced()) {
+      if ((wave & 3) == 0) return;
+      wave = (wave >> 2) * 3 + (wave & 3) - 1;
+      nw = 6;
+    }
     for (int inst = wave; inst < NI; inst += nw) {
       const int u = inst * 64 + lane, row = u / CPRD, ch = u % CPRD;
       const void* src = (u < UNITS && row < rows_end) ? (const void*)(base + (size_t)row * ld + ch * (16 / (int)sizeof(T))) : (const void*)v4h_zero_page;
@@ -255,11 +289,19 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
     const int it_next = attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H);
 #pragma unroll
     for (int s2 = 0; s2 < C::NKF; ++s2) xq[s2] = xq_next[s2];
+    V4H_STAMP(n, 0);
+#ifdef V4H_ATTN_STAMPS
+    if ((threadIdx.x & 63) == 0 && n < 4) v4h_attn_arrive[(blockIdx.x * 4 + n) * 16 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V4H_STAMP(n, 7);
+#endif
     __syncthreads();  // this item's K/V landed (vmcnt(0)); everyone is done with the buffer the next DMA overwrites
+    V4H_STAMP(n, 1);
     if (it_next >= 0) {
       stage_item(it_next, buf ^ 1);
       load_row_frags<T, DH>(xq_next, item_base(it_next), ld, wave * 16, active ? Tn : 0, lane);
     }
+    V4H_STAMP(n, 2);
     if (active) {
       const T* sK = reinterpret_cast<const T*>(smem + buf * 2 * DI::BYTES);
       const T* sV = reinterpret_cast<const T*>(smem + buf * 2 * DI::BYTES + DI::BYTES);
@@ -285,6 +327,7 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
       }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      V4H_STAMP(n, 3);
       float rs = 0.f;
 #pragma unroll
       for (int jt = 0; jt < C::NJT; ++jt)
@@ -295,6 +338,7 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
         }
       rs += __shfl_xor(rs, 16, 64);
       rs += __shfl_xor(rs, 32, 64);
+      V4H_STAMP(n, 4);
       f32x4 oacc[C::NDT];
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -304,6 +348,7 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 #pragma unroll
         for (int dt = 0; dt < C::NDT; ++dt) oacc[dt] = mma(frag_kstrided2(sV, DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
       }
+      V4H_STAMP(n, 5);
       const int q = wave * 16 + c;
       {
         const float inv = 1.0f / rs;
@@ -318,6 +363,7 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
         }
         if (q < Tn && g == 0 && lse) lse[((size_t)b * H + h) * Tn + q] = mx + __logf(rs);
       }
+      V4H_STAMP(n, 6);
     }
     it = it_next;
   }
