@@ -1,0 +1,34 @@
+"""Copy the summaries of a tools/refresh_profiles.sh run (gpurun_out/refresh_<tag>/) into profiles/ under round-stable names and rebuild the all-workload table.
+usage: python tools/collect_profiles.py <tag> [round prefix, default r02]"""
+import json, os, shutil, sys
+
+tag = sys.argv[1]
+rp = sys.argv[2] if len(sys.argv) > 2 else "r02"
+R = f"gpurun_out/refresh_{tag}"
+for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"),
+                 ("step_pmc_counters.md", f"{rp}_step_pmc_counters.md"), ("step_hbm_traffic.json", "step_hbm_traffic.json"), ("bench_final_bf16.json", f"{rp}_bench_final_bf16.json"),
+                 ("ab_in_context.txt", f"{rp}_ab_in_context_{tag}.txt")):
+    if os.path.exists(f"{R}/{src}"):
+        shutil.copy(f"{R}/{src}", f"profiles/{dst}")
+if os.path.exists(f"{R}/gemm2_ablation.txt"):
+    hdr = open(f"profiles/{rp}_gemm2_ablation.txt").read().split("\n\n")[0] + "\n\n" if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""
+    body = "\n".join(l for l in open(f"{R}/gemm2_ablation.txt").read().splitlines() if "amdgpu.ids" not in l)
+    open(f"profiles/{rp}_gemm2_ablation.txt", "w").write(hdr + body + "\n")
+names = {"ds2": "bench_final_bf16.json", "ds3": "bench_ds3.json", "ds2_d2": "bench_ds2_d2.json", "lemurs": "bench_lemurs.json", "ds1_photons": "bench_ds1_photons.json",
+         "ds1_pions": "bench_ds1_pions.json", "calogan": "bench_calogan.json", "calohad": "bench_calohad.json", "ds2 f32 mode": "bench_ds2_f32.json",
+         "ds2, collectives forced on (1 rank)": "bench_ds2_forced_collectives.json"}
+out = [f"# bench.py on one MI355X, round 2 final build (tools/refresh_profiles.sh {tag}; bf16 mode unless noted)", "",
+       "| workload | per-GPU batch | steps/s | ms/step | TFLOP/s | fraction of the dense MFMA spec peak |", "|---|---|---|---|---|---|"]
+for k, f in names.items():
+    r = json.loads(open(f"{R}/{f}").read().strip().splitlines()[-1])
+    out.append(f"| {k} ({r['config']['workload']}) | {r['config']['per_gpu_batch']} | {r['value']} | {r['ms_per_step']} | {r['roofline']['achieved']} | {r['roofline']['frac']} |")
+r = json.loads(open(f"{R}/bench_final_bf16.json").read().strip().splitlines()[-1])
+s = r["sampling"]
+out += ["", f"Sampling (BASELINE config 5; ds2, batch 256, bf16): RK4 step 0.05 (80 evaluations) {s['rk4']['showers_per_s']} showers/s = 100 k in {s['rk4']['s_per_100k']} s, "
+            f"{s['rk4']['tflops']} TFLOP/s; Heun (40 evaluations) {s['heun2']['showers_per_s']} showers/s = 100 k in {s['heun2']['s_per_100k']} s.",
+        f"CPU oracle on the same box ({r['cpu_baseline']['cpu']}): {r['cpu_baseline']['value']} steps/s on {r['cpu_baseline']['cores']} threads; "
+        f"{r['cpu_baseline']['one_thread']['value']} steps/s on one thread ({r['cpu_baseline']['one_thread']['sample']}).",
+        f"HBM traffic of one update step (PMC, same build): {r['roofline']['traffic']/1e9:.2f} GB.",
+        "Contraction rates inside this run (`gemm_ops`): " + "; ".join(f"{k} {v['us']} us = {v['tflops']} TFLOP/s" for k, v in r["gemm_ops"].items()) + "."]
+open(f"profiles/{rp}_bench_all_workloads.md", "w").write("\n".join(out) + "\n")
+print("\n".join(out))
