@@ -169,34 +169,33 @@ def op_rates(mode, BT, device, reps=20):
     if BT % 135 == 0:  # (ds2 / LEMURS token count; other workloads: per-kernel figures only)
         H, dh, D = 6, 80, 480
         Tn = 135
-        if True:
-            Bn = BT // Tn
-            u = torch.randn((BT, D), device=device).to(dt)
-            wq = torch.randn((3 * D, D), device=device).to(dt)
-            wp = torch.randn((D, D), device=device).to(dt)
-            qkv = torch.empty((BT, 3 * D), device=device, dtype=dt)
-            o = torch.empty((BT, D), device=device, dtype=dt)
-            y = torch.empty((BT, D), device=device, dtype=dt)
-            lse = torch.empty((Bn, H, Tn), device=device, dtype=torch.float32)
-            s = _lib.stream_ptr(device)
+        Bn = BT // Tn
+        u = torch.randn((BT, D), device=device).to(dt)
+        wq = torch.randn((3 * D, D), device=device).to(dt)
+        wp = torch.randn((D, D), device=device).to(dt)
+        qkv = torch.empty((BT, 3 * D), device=device, dtype=dt)
+        o = torch.empty((BT, D), device=device, dtype=dt)
+        y = torch.empty((BT, D), device=device, dtype=dt)
+        lse = torch.empty((Bn, H, Tn), device=device, dtype=torch.float32)
+        s = _lib.stream_ptr(device)
 
-            def block():
-                _lib.check(lib.v4h_op_gemm(_lib.MODES[mode], _lib.ptr(u), D, 0, _lib.ptr(wq), D, 0, None, _lib.ptr(qkv), 3 * D, 0, BT, 3 * D, D, 1, None, s))
-                _lib.check(lib.v4h_op_attention_fwd(_lib.MODES[mode], _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse), Bn, Tn, H, dh, s))
-                _lib.check(lib.v4h_op_gemm(_lib.MODES[mode], _lib.ptr(o), D, 0, _lib.ptr(wp), D, 0, None, _lib.ptr(y), D, 0, BT, D, D, 1, None, s))
+        def block():
+            _lib.check(lib.v4h_op_gemm(_lib.MODES[mode], _lib.ptr(u), D, 0, _lib.ptr(wq), D, 0, None, _lib.ptr(qkv), 3 * D, 0, BT, 3 * D, D, 1, None, s))
+            _lib.check(lib.v4h_op_attention_fwd(_lib.MODES[mode], _lib.ptr(qkv), _lib.ptr(o), _lib.ptr(lse), Bn, Tn, H, dh, s))
+            _lib.check(lib.v4h_op_gemm(_lib.MODES[mode], _lib.ptr(o), D, 0, _lib.ptr(wp), D, 0, None, _lib.ptr(y), D, 0, BT, D, D, 1, None, s))
 
-            for _ in range(3):
-                block()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(reps):
-                block()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            fl = 2.0 * BT * D * 3 * D + 4.0 * Bn * H * Tn * Tn * dh + 2.0 * BT * D * D
-            out["attention block fwd (qkv + attention + proj)"] = {"us": round(us, 2), "tflops": round(fl / us / 1e6, 1),
-                                                                    "frac_of_spec_peak": round(fl / us / 1e6 / (BF16_DENSE_PEAK_TFLOPS if mode == "bf16" else F32_MFMA_PEAK_TFLOPS), 4)}
+        for _ in range(3):
+            block()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            block()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        fl = 2.0 * BT * D * 3 * D + 4.0 * Bn * H * Tn * Tn * dh + 2.0 * BT * D * D
+        out["attention block fwd (qkv + attention + proj)"] = {"us": round(us, 2), "tflops": round(fl / us / 1e6, 1),
+                                                                "frac_of_spec_peak": round(fl / us / 1e6 / (BF16_DENSE_PEAK_TFLOPS if mode == "bf16" else F32_MFMA_PEAK_TFLOPS), 4)}
     # the dominant kernel of the step: the split-K weight gradients (dW = dY^T X over the tokens; partial slabs + ordered reduce, bias-gradient column sums on)
     for name, (I, J) in {"wgrad qkv 1440x480": (1440, 480), "wgrad proj 480x480": (480, 480), "wgrad fc1 1920x480": (1920, 480), "wgrad fc2 480x1920": (480, 1920)}.items():
         sk = 8 if I * J >= 40 * 96 * 160 else 16

@@ -194,7 +194,7 @@ def _int_operands(shape, gen, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=gen, device=U.DEV).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])  # 1: 128 x 160 two-workgroup kernel (v4h_gemm.h), 2: 256 x 160 ring kernel (v4h_gemm2.h)
+@pytest.mark.parametrize("kernel", [1, 2, 9])  # 1: 128 x 160 two-workgroup kernel (v4h_gemm.h), 2: 256 x 160 ring kernel (v4h_gemm2.h), 9: its ping-pong schedule
 def test_wgrad_slab_operator_exact(kernel):
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(5)
@@ -214,14 +214,16 @@ def test_wgrad_slab_operator_exact(kernel):
         lib.v4h_debug_set_gemm_cfg(0, -1)
 
 
+@pytest.mark.parametrize("kernel", [2, 9])  # lock-step and ping-pong schedule
 @pytest.mark.parametrize("qks", [0, 1])
-def test_ring_kernel_forward_and_dgrad_exact(qks):
-    """v4h_gemm2.h through v4h_op_gemm: K tails (K % 64 != 0), a partial last row tile, several column tiles, bias."""
+def test_ring_kernel_forward_and_dgrad_exact(qks, kernel):
+    """v4h_gemm2.h through v4h_op_gemm: K tails (K % 64 != 0), a partial last row tile, several column tiles, bias; enough row tiles that persistent
+    workgroups walk several tiles each (tile seams, bias slots of both parities)."""
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(6)
-    lib.v4h_debug_set_gemm_cfg(0, 2000)
+    lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
     try:
-        for I, J, K in ((2500, 480, 480), (2304, 320, 1440), (4100, 160, 200)):
+        for I, J, K in ((2500, 480, 480), (2304, 320, 1440), (4100, 160, 200), (40000, 480, 224)):
             P = _int_operands((I, K), gen)
             Q = _int_operands((K, J) if qks else (J, K), gen)
             bias = torch.randint(-4, 5, (J,), generator=gen, device=U.DEV).float()
@@ -231,6 +233,32 @@ def test_ring_kernel_forward_and_dgrad_exact(qks):
             assert torch.equal(out.float(), want.to(torch.bfloat16).float()), (I, J, K)
     finally:
         lib.v4h_debug_set_gemm_cfg(0, -1)
+
+
+def test_update_step_on_the_ping_pong_kernel_matches_the_default_dispatch():
+    """Every epilogue the ring kernel has (plain store, GELU with its saved derivative, the DGELU dgrad, split-K slabs with bias sums) inside one
+    loss + backward at a token count above its threshold: gradients against the two-workgroup kernel's on the same inputs.  Both accumulate each
+    output element over K in the same order, so they agree to rounding of the bf16 intermediates."""
+    lib = _lib.load()
+    cfg = O.ds2(2)
+    fill = O.golden_fill(cfg)
+    x, c, g = O.synthetic_batch(cfg, 24, 11)  # 24 x 135 = 3240 tokens
+    t, x0 = O.synthetic_noise(cfg, 24, g)
+    x, c, t, x0 = x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV)
+    res = {}
+    for kernel in (1, 9):
+        lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+        try:
+            model = U.build_models(cfg, "bf16", fill)
+            loss = model._loss_from_noise(x, c, t, x0)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[kernel] = (loss.item(), {k: v.clone() for k, v in U.named_grads(model).items()})
+        finally:
+            lib.v4h_debug_set_gemm_cfg(0, -1)
+    assert abs(res[1][0] - res[9][0]) < 2e-3 * abs(res[1][0])
+    for k, ref in res[1][1].items():
+        assert U.rel_err(res[9][1][k], ref) < 2e-2, k
 
 
 # ---------------------------------------------------------------------------------------------------------------- hipGraph capture

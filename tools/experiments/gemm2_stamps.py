@@ -1,0 +1,48 @@
+"""Slot timeline of the ping-pong ring contraction (diagnostic build: V4H_EXTRA_FLAGS=-DV4H_GEMM2_STAMPS python -m vit4hep_amd.build --force).
+Stamps (shader clock) per wave and stage: 0 load slot starts, 1 fragments in registers / DMA share and (at a seam) epilogue issued, 2 after the counted vmcnt wait
+(half 1), 3 after the barrier = matrix slot starts, 4 MFMAs issued, 5 after the counted vmcnt wait (half 0); the next stage's 0 is after the second barrier.
+usage (GPU box): python tools/experiments/gemm2_stamps.py [fc1|qkv|fc2|proj] [ver]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from vit4hep_amd import _lib
+
+which = sys.argv[1] if len(sys.argv) > 1 else "fc1"
+ver = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH)
+dev = "cuda:0"
+BT = 17280
+J, K = {"fc1": (1920, 480), "qkv": (1440, 480), "fc2": (480, 1920), "proj": (480, 480)}[which]
+dt = torch.bfloat16
+P = torch.randn((BT, K), device=dev).to(dt)
+Q = torch.randn((J, K), device=dev).to(dt)
+bias = torch.randn(J, device=dev)
+out = torch.empty((BT, J), device=dev, dtype=dt)
+s = _lib.stream_ptr(dev)
+lib.v4h_debug_set_gemm_cfg(0, 1000 * ver)
+args = (_lib.MODES["bf16"], _lib.ptr(P), K, 0, _lib.ptr(Q), K, 0, _lib.ptr(bias), _lib.ptr(out), J, 0, BT, J, K, 1, None, s)
+for _ in range(5):
+    _lib.check(lib.v4h_op_gemm(*args))
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); _lib.check(lib.v4h_op_gemm(*args)); e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3
+FIRST, NST, NK = 3, 8, 8
+buf = np.zeros(256 * 8 * NST * NK, dtype=np.uint32)
+assert raw.v4h_debug_gemm2_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
+st = buf.reshape(256, 8, NST, NK)
+print(f"{which}: one call {us:.1f} us (stamped build)")
+nt = (K + 63) // 64
+names = ["load-slot work (frag reads, DMA issue, seam: epilogue)", "vmcnt wait (half 1)", "barrier wait", "MFMA issue (40)", "vmcnt wait (half 0)", "barrier wait"]
+dif = lambda x, y: ((x.astype(np.int64) - y.astype(np.int64)) & 0xFFFFFFFF)
+for half in (0, 1):
+    w = st[:, 4 * half:4 * half + 4]          # (256, 4, NST, 6)
+    nxt0 = np.concatenate([w[:, :, 1:, 0], w[:, :, -1:, 5]], axis=2)
+    d = [dif(w[..., 1], w[..., 0]), dif(w[..., 2], w[..., 1]), dif(w[..., 3], w[..., 2]), dif(w[..., 4], w[..., 3]), dif(w[..., 5], w[..., 4]), dif(nxt0, w[..., 5])]
+    print(f"half {half}: median clocks per stage (t = stage within its tile; {nt} stages per tile), over all workgroups and the half's 4 waves")
+    for n in range(NST - 1):
+        dma = dif(w[..., 6], w[..., 0])[:, :, n]
+        extra = f" [DMA issue {int(np.median(dma))}]" if w[..., 6].any() else ""
+        print(f"  stage {FIRST + n} (t={(FIRST + n) % nt}):{extra} " + "; ".join(f"{nm.split(' (')[0]} {int(np.median(x[:, :, n]))}" for nm, x in zip(names, d)) + f"  | stage total {int(np.median(dif(nxt0, w[..., 0])[:, :, n]))}")
+lib.v4h_debug_set_gemm_cfg(0, -1)

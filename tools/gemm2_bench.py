@@ -74,8 +74,8 @@ for nm, I, J, K, pks, qks, sk in shapes:
     fn, ref, outs, reset = make(nm, I, J, K, pks, qks, sk)
     r = ref()
     res = {}
-    for ver in (1, 2):
-        lib.v4h_debug_set_gemm_cfg(0, 1000 * ver)  # 1000 = old kernel, 2000 = new kernel
+    for ver in (1, 2, 9):
+        lib.v4h_debug_set_gemm_cfg(0, 1000 * ver)  # 1000 = two-workgroup kernel, 2000 = ring kernel (lock-step), 9000 = ring kernel, ping-pong schedule
         reset()
         fn()
         torch.cuda.synchronize()
@@ -83,16 +83,17 @@ for nm, I, J, K, pks, qks, sk in shapes:
         for o, rr in zip(outs(), r):
             errs.append(((o.float() - rr).abs().max() / rr.abs().max()).item())
         res[ver] = [max(errs)]
-    abl = (3, 4, 5, 6, 7, 8) if (not pks and not qks and os.environ.get("ABL")) else ()   # 3000: no DMA in loop; 4000: no stores; 5000: neither; 6000: + no fragment reads; 7000: no DMA/stores/barrier; 8000: MFMA only
+    abl = (3, 4, 5, 6, 7, 8, 10, 11, 12) if (not pks and not qks and os.environ.get("ABL")) else ()  # 10000/11000/12000: ping-pong schedule without DMA in the loop / without stores / without both
+    #   # 3000: no DMA in loop; 4000: no stores; 5000: neither; 6000: + no fragment reads; 7000: no DMA/stores/barrier; 8000: MFMA only
     for ver in abl:
         res[ver] = [0.0]
     for _ in range(ROUNDS):
-        for ver in (1, 2) + abl:
+        for ver in (1, 2, 9) + abl:
             lib.v4h_debug_set_gemm_cfg(0, 1000 * ver)
             res[ver].append(timeit(fn))
     fl = 2.0 * I * J * K
-    t1, t2 = sorted(res[1][1:]), sorted(res[2][1:])
-    m1, m2 = t1[len(t1) // 2], t2[len(t2) // 2]
+    t1, t2, t9 = sorted(res[1][1:]), sorted(res[2][1:]), sorted(res[9][1:])
+    m1, m2, m9 = t1[len(t1) // 2], t2[len(t2) // 2], t9[len(t9) // 2]
     print(f"{nm:16s} I={I:6d} J={J:5d} K={K:6d} split={sk:2d} | old {m1:7.1f} us {fl/m1/1e6:7.1f} TF (min {t1[0]:6.1f}) err {res[1][0]:.1e} | new {m2:7.1f} us {fl/m2/1e6:7.1f} TF "
-          f"(min {t2[0]:6.1f}) err {res[2][0]:.1e} | x{m1/m2:.3f}" + "".join(f" | abl{v} {sorted(res[v][1:])[len(res[v][1:]) // 2]:6.1f} us" for v in abl), flush=True)
+          f"(min {t2[0]:6.1f}) err {res[2][0]:.1e} | x{m1/m2:.3f} | pp {m9:7.1f} us {fl/m9/1e6:7.1f} TF (min {t9[0]:6.1f}) err {res[9][0]:.1e} | x{m1/m9:.3f}" + "".join(f" | abl{v} {sorted(res[v][1:])[len(res[v][1:]) // 2]:6.1f} us" for v in abl), flush=True)
 lib.v4h_debug_set_gemm_cfg(0, -1)

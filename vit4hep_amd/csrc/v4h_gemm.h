@@ -130,6 +130,16 @@ V4H_DEV f32x8 swap_pair(f32x4 a, f32x4 b) {
   }
   return o;
 }
+// The same exchange on values already rounded to bf16: two swaps per tile pair instead of four (the lane permutation does not look at the contents).
+// Returns the 8 consecutive columns of the lane's row as 16 bytes.
+V4H_DEV u32x4 swap_pair_bf16(f32x4 a, f32x4 b) {
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  unsigned x01 = __builtin_bit_cast(unsigned, bf16x2_{(bf16)a[0], (bf16)a[1]}), x23 = __builtin_bit_cast(unsigned, bf16x2_{(bf16)a[2], (bf16)a[3]});
+  unsigned y01 = __builtin_bit_cast(unsigned, bf16x2_{(bf16)b[0], (bf16)b[1]}), y23 = __builtin_bit_cast(unsigned, bf16x2_{(bf16)b[2], (bf16)b[3]});
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x01), "+v"(y01));
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x23), "+v"(y23));
+  return u32x4{x01, x23, y01, y23};
+}
 V4H_DEV u32x4 pack_bf16x8(const f32x8& x) {
   bf16x8 o;
 #pragma unroll

@@ -112,6 +112,11 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if (epi == EPI_STORE && g_v2 == 5) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 7>>(a, 1, s, "gemm2_fwd/store/dbg7");
       if (epi == EPI_STORE && g_v2 == 6) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 11>>(a, 1, s, "gemm2_fwd/store/dbg11");
       if (epi == EPI_STORE && g_v2 == 7) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 15>>(a, 1, s, "gemm2_fwd/store/dbg15");
+      if (epi == EPI_STORE && g_v2 == 9) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1, true>>(a, 1, s, "gemm2pp_fwd/store/dbg1");
+      if (epi == EPI_STORE && g_v2 == 10) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2, true>>(a, 1, s, "gemm2pp_fwd/store/dbg2");
+      if (epi == EPI_STORE && g_v2 == 11) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 3, true>>(a, 1, s, "gemm2pp_fwd/store/dbg3");
+      if (epi == EPI_STORE && g_v2 == 8) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_fwd/store");
+      if (epi == EPI_GELU && g_v2 == 8 && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
       if (epi == EPI_STORE) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
       if (epi == EPI_GELU && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
     }
@@ -140,6 +145,8 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
 template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (v2_ok(a, a.K)) {
+      if (epi == EPI_STORE && g_v2 == 8) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/store");
+      if (epi == EPI_DGELU && g_v2 == 8 && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/dgelu");
       if (epi == EPI_STORE) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
       if (epi == EPI_DGELU && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");
     }
@@ -175,7 +182,8 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   klen = (klen + bk - 1) / bk * bk;
   *nz_out = (a.K + klen - 1) / klen;
   if (m == MODE_BF16 && g_v2 > 0 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
-    return v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
+    return g_v2 == 8 ? v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true, 0, true>>(a, splitk, s, "gemm2pp_wgrad/slab")
+                     : v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the
   // split the runtime uses); 96 x 160 is 2-4 % ahead on three of the four block shapes
   if (m == MODE_BF16 && (g_cfg_wgrad == 13 || (g_strips & 8))) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 96, 160, 64, 2, 2, EPI_SLAB_F32, true, 9>>(a, splitk, s, "gemm_wgrad/slab/strips");
@@ -183,6 +191,12 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   if (m == MODE_BF16) return v4h_gemm_launch<GemmCfg<bf16, bf16, true, true, 96, 160, 64, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
   return v4h_gemm_launch<GemmCfg<float, float, true, true, 160, 96, 32, 2, 2, EPI_SLAB_F32, true>>(a, splitk, s, "gemm_wgrad/slab");
 }
+
+#ifdef V4H_GEMM2_STAMPS
+extern "C" int v4h_debug_gemm2_stamps(void* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(v4h_gemm2_stamp_buf), sizeof(v4h_gemm2_stamp_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 void debug_set_gemm_cfg(int cfg, int cfg_wgrad) {
   if (cfg_wgrad < 0) { g_v2 = -1; cfg_wgrad = 0; }  // back to the default choice

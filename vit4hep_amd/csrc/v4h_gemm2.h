@@ -62,10 +62,11 @@ template <int COLS> struct FragKS {  // K-strided image [k][COLS], transposed re
   }
 };
 
-template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0> struct Gemm2Cfg {
+template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0, bool PP_ = false> struct Gemm2Cfg {
   using T = bf16;
   static constexpr bool PKS = PKS_, QKS = QKS_, COLSUM = COLSUM_;
   static constexpr int EPI = EPI_, DBG = DBG_;
+  static constexpr bool PP = PP_;  // ping-pong schedule: the two waves of a SIMD alternate a load slot and a matrix slot
   static constexpr int BI = 256, BJ = 160, BK = 64, WI = 4, WJ = 2, NW = 8, NT = 512, WTI = 64, WTJ = 80, TI = 4, TJ = 5, NS = 3;
   using ImgP = typename std::conditional<PKS, ImgKStrided<bf16, BI, BK, NW>, ImgKContig<bf16, BI, BK, NW>>::type;
   using ImgQ = typename std::conditional<QKS, ImgKStrided<bf16, BJ, BK, NW>, ImgKContig<bf16, BJ, BK, NW>>::type;
@@ -81,23 +82,49 @@ template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0> struct Gem
   static_assert(EPI_OPS > 0, "epilogue not built for the 256 x 160 kernel");
 };
 
+// `s_waitcnt vmcnt(n)` for a wave-uniform n that is only known at run time (gfx9 has no register form of the instruction): a computed jump into a table of
+// 49 two-instruction entries - eight scalar instructions in all.  (Written as a C++ switch the compiler lowers it to a chain of some 200 scalar compares and
+// branches, about 450 clocks on the critical path of every K-step: tools/experiments/gemm2_stamps.py.)  n above 48 waits for 48: only ever conservative.
 V4H_DEV void wait_vmcnt64(int n) {
-  // steady state: exactly one younger stage in flight (6 or 7 DMA instructions of this wave)
-  if (__builtin_expect(n == 7, 1)) { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); return; }
-  if (__builtin_expect(n == 6, 1)) { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); return; }
-#define V4H_VM_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    V4H_VM_CASE(0) V4H_VM_CASE(1) V4H_VM_CASE(2) V4H_VM_CASE(3) V4H_VM_CASE(4) V4H_VM_CASE(5) V4H_VM_CASE(6) V4H_VM_CASE(7) V4H_VM_CASE(8)
-    V4H_VM_CASE(9) V4H_VM_CASE(10) V4H_VM_CASE(11) V4H_VM_CASE(12) V4H_VM_CASE(13) V4H_VM_CASE(14) V4H_VM_CASE(15) V4H_VM_CASE(16)
-    V4H_VM_CASE(17) V4H_VM_CASE(18) V4H_VM_CASE(19) V4H_VM_CASE(20) V4H_VM_CASE(21) V4H_VM_CASE(22) V4H_VM_CASE(23) V4H_VM_CASE(24)
-    V4H_VM_CASE(25) V4H_VM_CASE(26) V4H_VM_CASE(27) V4H_VM_CASE(28) V4H_VM_CASE(29) V4H_VM_CASE(30) V4H_VM_CASE(31) V4H_VM_CASE(32)
-    V4H_VM_CASE(33) V4H_VM_CASE(34) V4H_VM_CASE(35) V4H_VM_CASE(36) V4H_VM_CASE(37) V4H_VM_CASE(38) V4H_VM_CASE(39) V4H_VM_CASE(40)
-    V4H_VM_CASE(41) V4H_VM_CASE(42) V4H_VM_CASE(43) V4H_VM_CASE(44) V4H_VM_CASE(45) V4H_VM_CASE(46) V4H_VM_CASE(47) V4H_VM_CASE(48)
-    default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;  // fewer allowed in flight than there are: only ever conservative
-  }
-#undef V4H_VM_CASE
+#define V4H_VM_ROW(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch 1f\n\t"
+  asm volatile(
+      "s_min_u32 s90, %0, 48\n\t"
+      "s_lshl_b32 s90, s90, 3\n\t"
+      "s_add_u32 s90, s90, 12\n\t"
+      "s_getpc_b64 s[92:93]\n\t"
+      "s_add_u32 s92, s92, s90\n\t"
+      "s_addc_u32 s93, s93, 0\n\t"
+      "s_setpc_b64 s[92:93]\n\t"
+      V4H_VM_ROW(0) V4H_VM_ROW(1) V4H_VM_ROW(2) V4H_VM_ROW(3) V4H_VM_ROW(4) V4H_VM_ROW(5) V4H_VM_ROW(6) V4H_VM_ROW(7) V4H_VM_ROW(8) V4H_VM_ROW(9)
+      V4H_VM_ROW(10) V4H_VM_ROW(11) V4H_VM_ROW(12) V4H_VM_ROW(13) V4H_VM_ROW(14) V4H_VM_ROW(15) V4H_VM_ROW(16) V4H_VM_ROW(17) V4H_VM_ROW(18) V4H_VM_ROW(19)
+      V4H_VM_ROW(20) V4H_VM_ROW(21) V4H_VM_ROW(22) V4H_VM_ROW(23) V4H_VM_ROW(24) V4H_VM_ROW(25) V4H_VM_ROW(26) V4H_VM_ROW(27) V4H_VM_ROW(28) V4H_VM_ROW(29)
+      V4H_VM_ROW(30) V4H_VM_ROW(31) V4H_VM_ROW(32) V4H_VM_ROW(33) V4H_VM_ROW(34) V4H_VM_ROW(35) V4H_VM_ROW(36) V4H_VM_ROW(37) V4H_VM_ROW(38) V4H_VM_ROW(39)
+      V4H_VM_ROW(40) V4H_VM_ROW(41) V4H_VM_ROW(42) V4H_VM_ROW(43) V4H_VM_ROW(44) V4H_VM_ROW(45) V4H_VM_ROW(46) V4H_VM_ROW(47) V4H_VM_ROW(48)
+      "1:"
+      :
+      : "s"(n)
+      : "s90", "s92", "s93", "scc", "memory");
+#undef V4H_VM_ROW
 }
 
+#ifdef V4H_GEMM2_STAMPS
+// Diagnostic build only (V4H_EXTRA_FLAGS=-DV4H_GEMM2_STAMPS): every wave of the ping-pong schedule stamps the shader clock at the boundaries of its slots for
+// the stages 3..10 of its workgroup (a tile seam in the middle), first into the last 2 KB of the CU's LDS - no vector-memory instruction, so the counted
+// waits are untouched - and copies them out at the end (tools/experiments/gemm2_stamps.py).
+constexpr int G2_ST_FIRST = 3, G2_ST_N = 8, G2_ST_K = 8;
+__device__ unsigned v4h_gemm2_stamp_buf[256 * 8 * G2_ST_N * G2_ST_K];
+#define V4H_G2_STAMP(k)                                                                                                             \
+  do {                                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+    unsigned long long now_;                                                                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory");                                                  \
+    if (lane == 0 && st_n >= G2_ST_FIRST && st_n < G2_ST_FIRST + G2_ST_N)                                                            \
+      reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[(wave * G2_ST_N + st_n - G2_ST_FIRST) * G2_ST_K + (k)] = (unsigned)now_;             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                              \
+  } while (0)
+#else
+#define V4H_G2_STAMP(k) do { } while (0)
+#endif
 
 template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,34 +160,40 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
   // ------------------------------------------------------------------ request side: stages of this workgroup's tile list, in order
   typename C::ImgP stP;
   typename C::ImgQ stQ;
-  const int cntPQ = sgpr(C::ImgP::count(wave) + C::ImgQ::count(wave));  // DMA instructions of this wave per stage
   int rv = blockIdx.x, r_ti = 0, r_tj = 0, r_tz = 0;
   bool r_valid = decode(rv, r_ti, r_tj, r_tz);
   int r_t = 0, r_nt = 0, r_kb = 0, r_ke = 0, r_slot = 0, r_par = 0, r_count = 0;
-  auto request = [&]() -> int {  // issues the next stage; returns the number of vector-memory instructions this wave issued for it
+  // issue(): the DMA instructions of the next stage (returns how many this wave issued); advance(): the walk to the stage after it - at a tile
+  // change the decode of the next tile (integer divisions) and both sets of per-lane source pointers.  The lock-step schedule runs them back to
+  // back; the ping-pong schedule issues in the load slot and advances in the matrix slot, where scalar and vector ALU work hides between MFMAs.
+  auto tile_setup = [&]() {
+    r_kb = r_tz * a.klen;
+    r_ke = min(a.K, r_kb + a.klen);
+    r_nt = (r_ke - r_kb + C::BK - 1) >> 6;
+    static_assert(C::BK == 64, "shift");
+    stP.init(gP, a.ldp, r_ti * C::BI, r_kb, a.I, wave, lane);
+    stQ.init(gQ, a.ldq, r_tj * C::BJ, r_kb, a.J, wave, lane);
+  };
+  if (r_valid) tile_setup();
+  auto issue = [&]() -> int {
     if (!r_valid) return 0;
-    int n = cntPQ;
-    if (r_t == 0) {
-      r_kb = r_tz * a.klen;
-      r_ke = min(a.K, r_kb + a.klen);
-      r_nt = (r_ke - r_kb + C::BK - 1) >> 6;
-      static_assert(C::BK == 64, "shift");
-      stP.init(gP, a.ldp, r_ti * C::BI, r_kb, a.I, wave, lane);
-      stQ.init(gQ, a.ldq, r_tj * C::BJ, r_kb, a.J, wave, lane);
-      if (C::EPI != EPI_SLAB_F32 && a.e.bias != nullptr && wave == 0) {  // the tile's bias slice travels with its first stage
-        const int j = r_tj * C::BJ + 4 * lane;
-        const void* src = (4 * lane < C::BJ && j + 4 <= a.J) ? (const void*)(a.e.bias + j) : (const void*)v4h_zero_page;
-        dma16(src, smem + C::BIAS_OFF + r_par * C::BIAS_SLOT);
-        ++n;
-      }
+    int n = 0;
+    if (r_t == 0 && C::EPI != EPI_SLAB_F32 && a.e.bias != nullptr && wave == 0) {  // the tile's bias slice travels with its first stage
+      const int j = r_tj * C::BJ + 4 * lane;
+      const void* src = (4 * lane < C::BJ && j + 4 <= a.J) ? (const void*)(a.e.bias + j) : (const void*)v4h_zero_page;
+      dma16(src, smem + C::BIAS_OFF + r_par * C::BIAS_SLOT);
+      ++n;
     }
-    const int k0 = r_kb + r_t * C::BK;
     if (!(C::DBG & 1) || r_count < C::NS) {  // DBG 1 (ablation): only the first ring fill is really staged
+      const int k0 = r_kb + r_t * C::BK;
       stP.stage(smem + r_slot * C::STAGE, k0, r_ke, a.ldp, wave);
       stQ.stage(smem + r_slot * C::STAGE + C::P_BYTES, k0, r_ke, a.ldq, wave);
-    } else {
-      n = 0;
+      n += C::ImgP::count(wave) + C::ImgQ::count(wave);
     }
+    return sgpr(n);
+  };
+  auto advance = [&]() {
+    if (!r_valid) return;
     ++r_count;
     r_slot = r_slot == C::NS - 1 ? 0 : r_slot + 1;
     if (++r_t == r_nt) {
@@ -168,8 +201,13 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       r_par ^= 1;
       rv += gridDim.x;
       r_valid = decode(rv, r_ti, r_tj, r_tz);
+      if (r_valid) tile_setup();
     }
-    return sgpr(n);
+  };
+  auto request = [&]() -> int {
+    const int n = issue();
+    advance();
+    return n;
   };
 
   // ------------------------------------------------------------------ compute side
@@ -231,6 +269,206 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
     }
   };
 
+  // ---- epilogue: registers -> memory, no LDS.  Chunk n < 8: tiles (x, 2q), (x, 2q + 1), x = n >> 1, q = n & 1 - 64 contiguous bytes of bf16
+  // per row and instruction; n >= 8: the odd fifth column tile, paired over the row strips x = 2 (n - 8) and x + 1.  J is a whole number of
+  // 160-column tiles (launcher), rows beyond I fall outside the buffer and are dropped by its bounds check: no predicate anywhere.
+  auto epilogue = [&](int ti, int tj, int tz) -> int {
+    const int ge = g & 1, gh = g >> 1;
+    const int rowA = ti * C::BI + wi * C::WTI + c, colA = tj * C::BJ + wj * C::WTJ + 16 * ge + 8 * gh;
+    const int rowB = rowA + 16 * ge, colB = tj * C::BJ + wj * C::WTJ + 64 + 8 * gh;
+    auto chunk_val = [&](int n) -> f32x8 {
+      if (n < 8) return swap_pair(acc[n >> 1][2 * (n & 1)], acc[n >> 1][2 * (n & 1) + 1]);
+      return swap_pair(acc[2 * (n - 8)][4], acc[2 * (n - 8) + 1][4]);
+    };
+    auto chunk_tiles = [&](int n, f32x4& ta, f32x4& tb) {  // the two accumulator tiles of chunk n
+      if (n < 8) { ta = acc[n >> 1][2 * (n & 1)]; tb = acc[n >> 1][2 * (n & 1) + 1]; }
+      else { ta = acc[2 * (n - 8)][4]; tb = acc[2 * (n - 8) + 1][4]; }
+    };
+    // element offset of chunk n in a row-major tensor of row stride ld, from the lane's two base offsets
+    auto chunk_off = [&](int n, unsigned offA, unsigned offB, int ld) -> unsigned {
+      return n < 8 ? offA + (unsigned)((n >> 1) * 16 * ld + (n & 1) * 32) : offB + (unsigned)(2 * (n - 8) * 16 * ld);
+    };
+    if constexpr ((C::DBG & 2) != 0) {  // ablation: every MFMA live, one 16-byte store per lane and tile
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int x = 0; x < C::TI; ++x)
+#pragma unroll
+        for (int y = 0; y < C::TJ; ++y) sum += acc[x][y];
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), ro, (unsigned)(rowA * a.e.ldo + colA) * 2u, 0, 0);
+    } else if constexpr (C::EPI == EPI_STORE || C::EPI == EPI_GELU || C::EPI == EPI_DGELU) {
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
+      const unsigned oA = (unsigned)(rowA * a.e.ldo + colA), oB = (unsigned)(rowB * a.e.ldo + colB);
+      if constexpr (C::EPI == EPI_STORE) {
+#pragma unroll
+        for (int n = 0; n < C::NCHUNK; ++n)
+          __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(chunk_val(n)), ro, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, 0);
+      } else if constexpr (C::EPI == EPI_GELU) {  // out = gelu'(pre) (training only), out2 = gelu(pre)
+        const bool train = a.e.out != nullptr;
+        const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(a.e.out2, 0, (int)min((long)a.I * a.e.ldo2 * 2, 0x7FFFFFF0L), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, train ? (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L) : 0, 0x00020000);
+        const unsigned pA2 = (unsigned)(rowA * a.e.ldo2 + colA), pB2 = (unsigned)(rowB * a.e.ldo2 + colB);
+#pragma unroll
+        for (int n = 0; n < C::NCHUNK; ++n) {
+          f32x8 v = chunk_val(n), d;
+          if (train) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gelu_and_grad<bf16>(v.v[r], v.v[r], d.v[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { v.v[r] = gelu_only<bf16>(v.v[r]); d.v[r] = 0.f; }
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rd, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, 0);  // (inference: zero-sized buffer, dropped)
+          __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro2, chunk_off(n, pA2, pB2, a.e.ldo2) * 2u, 0, 0);
+        }
+      } else {  // EPI_DGELU: out = acc * aux
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.e.aux), 0, (int)min((long)a.I * a.e.ld_aux * 2, 0x7FFFFFF0L), 0x00020000);
+        const unsigned xA = (unsigned)(rowA * a.e.ld_aux + colA), xB = (unsigned)(rowB * a.e.ld_aux + colB);
+        // (requested here, five chunks at a time; the compiler's wait for them also retires the two stages in flight, which are older anyway)
+#pragma unroll
+        for (int h = 0; h < C::NCHUNK; h += 5) {
+          u32x4 raw[5];
+#pragma unroll
+          for (int n = 0; n < 5; ++n) raw[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(h + n, xA, xB, a.e.ld_aux) * 2u, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 5; ++n) {
+            f32x8 v = chunk_val(h + n);
+            const bf16x8 x = __builtin_bit_cast(bf16x8, raw[n]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v.v[r] *= (float)x[r];
+            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro, chunk_off(h + n, oA, oB, a.e.ldo) * 2u, 0, 0);
+          }
+        }
+      }
+    } else {  // EPI_SLAB_F32: split-K partial of the wgrad form, f32
+      float* slab = reinterpret_cast<float*>(a.e.out) + (size_t)tz * a.e.slab_stride;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min((long)a.I * a.e.ldo * 4, 0x7FFFFFF0L), 0x00020000);
+      const unsigned oA = (unsigned)(rowA * a.e.ldo + colA), oB = (unsigned)(rowB * a.e.ldo + colB);
+#pragma unroll
+      for (int n = 0; n < C::NCHUNK; ++n) {
+        const f32x8 v = chunk_val(n);
+        const unsigned off = chunk_off(n, oA, oB, a.e.ldo) * 4u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.v[0], v.v[1], v.v[2], v.v[3]}), ro, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.v[4], v.v[5], v.v[6], v.v[7]}), ro, off + 16u, 0, 0);
+      }
+    }
+    return (C::DBG & 2) ? 1 : C::EPI_OPS;
+  };
+
+  // ------------------------------------------------------------------ ping-pong schedule (C::PP)
+  // The waves w and w + 4 of a workgroup share a SIMD.  Time is cut into slots separated by one s_barrier each; in every slot one of the two
+  // runs a LOAD slot (both K = 32 fragment sets of a stage from LDS into registers, its share of the DMA of the stage two ahead, at a tile seam
+  // the previous tile's epilogue) while its partner runs a MATRIX slot (the 40 MFMAs of the stage it loaded one slot earlier): the matrix pipe
+  // of the SIMD always has a wave with nothing but MFMAs to issue, and the slow instructions (a global->LDS DMA instruction occupies the issuing
+  // wave for 60-180 cycles) sit in the partner's shadow.  Half 0 (waves 0..3) loads stage s in slot 2s and multiplies in slot 2s + 1, half 1
+  // one slot later.  Ring discipline: stage s + 2 goes into the slot of stage s - 1, which half 1 finished reading in slot 2s - 1; a wave makes
+  // sure its share of stage s + 1 has landed (counted vmcnt: everything it issued after that share may stay in flight) before the barrier that
+  // ends slot 2s + 1 - for half 0 that is the end of its matrix slot, for half 1 the end of its load slot.
+  if constexpr (C::PP) {
+    static_assert(!(C::DBG & ~3), "the other ablation builds belong to the lock-step schedule");
+    const int half = wave >> 2;
+    auto slot_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#ifdef V4H_GEMM2_STAMPS
+    int st_n = 0;
+#endif
+    // Counted waits: yo = vector-memory instructions this wave issued after the share of the stage that has to land next, yn = after its newest
+    // share.  (Measured and lost - fc1 forward 51.8 -> 54.5 us, dgrad fc1 38.5 -> 43.5: the Q part of a stage requested from inside the matrix
+    // slot, between the two MFMA groups, so that every slot carries 4 + 2..3 DMA instructions per SIMD: a DMA instruction costs its wave about
+    // 100 clocks, and in the matrix slot those are clocks in which the SIMD's only MFMA stream does not issue.)
+    int yo = 0, yn = 0;
+    {
+      request();
+      const int n1 = request();
+      wait_vmcnt64(n1);
+      slot_barrier();  // stage 0 is in LDS
+    }
+    if (half == 1) slot_barrier();  // slot 0: half 1 has nothing to multiply yet
+    int p_ti = 0, p_tj = 0, p_tz = 0;
+    bool have_prev = false;
+    for (;;) {
+      const int kb = tz * a.klen, ke = min(a.K, kb + a.klen);
+      const int nt = (ke - kb + C::BK - 1) >> 6;
+      const int cs_period = a.ntj * C::WJ, cs_duty = tj * C::WJ + wj;
+      int cs_phase = 0;
+      int nv = cv + gridDim.x, n_ti = 0, n_tj = 0, n_tz = 0;
+      const bool more = decode(nv, n_ti, n_tj, n_tz);
+      for (int t = 0; t < nt; ++t) {
+        // ---- load slot
+        V4H_G2_STAMP(0);
+        read_frags(pA, qA, c_slot, std::integral_constant<int, 0>{});
+        read_frags(pB, qB, c_slot, std::integral_constant<int, 1>{});
+        auto p_part = [&]() {
+          yo += issue();
+          yn = 0;
+        };
+        if (C::EPI != EPI_DGELU) p_part();  // (the DGELU epilogue loads: its waits would also wait for a DMA issued in front of it)
+        if (t == 0) {
+          if (have_prev) {
+            const int n = epilogue(p_ti, p_tj, p_tz);
+            yo += n;
+            yn += n;
+          }
+          init_acc(c_par);
+        }
+        if (C::EPI == EPI_DGELU) p_part();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the fragments are in registers, this wave is done with the stage
+        V4H_G2_STAMP(1);
+        if (half == 1) {
+          wait_vmcnt64(sgpr(yo));
+          yo = yn;
+        }
+        V4H_G2_STAMP(2);
+        slot_barrier();
+        V4H_G2_STAMP(3);
+        // ---- matrix slot
+        if constexpr (C::COLSUM) {
+          if (a.colsum != nullptr && cs_phase == cs_duty) {
+            colsum_slab(pA, ti * C::BI + wi * C::WTI);
+            yo += C::TI;
+            yn += C::TI;
+          }
+          if (++cs_phase == cs_period) cs_phase = 0;
+          if (a.colsum != nullptr && cs_phase == cs_duty) {
+            colsum_slab(pB, ti * C::BI + wi * C::WTI);
+            yo += C::TI;
+            yn += C::TI;
+          }
+          if (++cs_phase == cs_period) cs_phase = 0;
+        }
+        mfmas(pA, qA, 0, C::TI);
+        advance();  // (scalar and vector ALU work only: it issues between the MFMAs)
+        mfmas(pB, qB, 0, C::TI);
+        V4H_G2_STAMP(4);
+        if (half == 0) {
+          wait_vmcnt64(sgpr(yo));
+          yo = yn;
+        }
+        V4H_G2_STAMP(5);
+        slot_barrier();
+#ifdef V4H_GEMM2_STAMPS
+        ++st_n;
+#endif
+        c_slot = c_slot == C::NS - 1 ? 0 : c_slot + 1;
+      }
+      p_ti = ti; p_tj = tj; p_tz = tz;
+      have_prev = true;
+      if (!more) break;
+      cv = nv; ti = n_ti; tj = n_tj; tz = n_tz;
+      c_par ^= 1;
+    }
+    if (half == 0) slot_barrier();  // the slot in which half 1 multiplies its last stage
+    epilogue(p_ti, p_tj, p_tz);
+#ifdef V4H_GEMM2_STAMPS
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    v4h_gemm2_stamp_buf[(blockIdx.x * 8 + wave) * G2_ST_N * G2_ST_K + lane] = reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[wave * G2_ST_N * G2_ST_K + lane];
+#endif
+    return;
+  }
+
   // prologue: three stages in flight, wait for the first
   int last_cnt, e1 = 0, e2 = 0;
   {
@@ -291,87 +529,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       c_slot = n_slot;
     }
 
-    // ---- epilogue: registers -> memory, no LDS.  Chunk n < 8: tiles (x, 2q), (x, 2q + 1), x = n >> 1, q = n & 1 - 64 contiguous bytes of bf16
-    // per row and instruction; n >= 8: the odd fifth column tile, paired over the row strips x = 2 (n - 8) and x + 1.  J is a whole number of
-    // 160-column tiles (launcher), rows beyond I fall outside the buffer and are dropped by its bounds check: no predicate anywhere.
-    {
-      const int ge = g & 1, gh = g >> 1;
-      const int rowA = ti * C::BI + wi * C::WTI + c, colA = tj * C::BJ + wj * C::WTJ + 16 * ge + 8 * gh;
-      const int rowB = rowA + 16 * ge, colB = tj * C::BJ + wj * C::WTJ + 64 + 8 * gh;
-      auto chunk_val = [&](int n) -> f32x8 {
-        if (n < 8) return swap_pair(acc[n >> 1][2 * (n & 1)], acc[n >> 1][2 * (n & 1) + 1]);
-        return swap_pair(acc[2 * (n - 8)][4], acc[2 * (n - 8) + 1][4]);
-      };
-      // element offset of chunk n in a row-major tensor of row stride ld, from the lane's two base offsets
-      auto chunk_off = [&](int n, unsigned offA, unsigned offB, int ld) -> unsigned {
-        return n < 8 ? offA + (unsigned)((n >> 1) * 16 * ld + (n & 1) * 32) : offB + (unsigned)(2 * (n - 8) * 16 * ld);
-      };
-      if constexpr ((C::DBG & 2) != 0) {  // ablation: every MFMA live, one 16-byte store per lane and tile
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int x = 0; x < C::TI; ++x)
-#pragma unroll
-          for (int y = 0; y < C::TJ; ++y) sum += acc[x][y];
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), ro, (unsigned)(rowA * a.e.ldo + colA) * 2u, 0, 0);
-      } else if constexpr (C::EPI == EPI_STORE || C::EPI == EPI_GELU || C::EPI == EPI_DGELU) {
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
-        const unsigned oA = (unsigned)(rowA * a.e.ldo + colA), oB = (unsigned)(rowB * a.e.ldo + colB);
-        if constexpr (C::EPI == EPI_STORE) {
-#pragma unroll
-          for (int n = 0; n < C::NCHUNK; ++n)
-            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(chunk_val(n)), ro, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, 0);
-        } else if constexpr (C::EPI == EPI_GELU) {  // out = gelu'(pre) (training only), out2 = gelu(pre)
-          const bool train = a.e.out != nullptr;
-          const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(a.e.out2, 0, (int)min((long)a.I * a.e.ldo2 * 2, 0x7FFFFFF0L), 0x00020000);
-          const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, train ? (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L) : 0, 0x00020000);
-          const unsigned pA2 = (unsigned)(rowA * a.e.ldo2 + colA), pB2 = (unsigned)(rowB * a.e.ldo2 + colB);
-#pragma unroll
-          for (int n = 0; n < C::NCHUNK; ++n) {
-            f32x8 v = chunk_val(n), d;
-            if (train) {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) gelu_and_grad<bf16>(v.v[r], v.v[r], d.v[r]);
-            } else {
-#pragma unroll
-              for (int r = 0; r < 8; ++r) { v.v[r] = gelu_only<bf16>(v.v[r]); d.v[r] = 0.f; }
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rd, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, 0);  // (inference: zero-sized buffer, dropped)
-            __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro2, chunk_off(n, pA2, pB2, a.e.ldo2) * 2u, 0, 0);
-          }
-        } else {  // EPI_DGELU: out = acc * aux
-          const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.e.aux), 0, (int)min((long)a.I * a.e.ld_aux * 2, 0x7FFFFFF0L), 0x00020000);
-          const unsigned xA = (unsigned)(rowA * a.e.ld_aux + colA), xB = (unsigned)(rowB * a.e.ld_aux + colB);
-          // (requested here, five chunks at a time; the compiler's wait for them also retires the two stages in flight, which are older anyway)
-#pragma unroll
-          for (int h = 0; h < C::NCHUNK; h += 5) {
-            u32x4 raw[5];
-#pragma unroll
-            for (int n = 0; n < 5; ++n) raw[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(h + n, xA, xB, a.e.ld_aux) * 2u, 0, 0);
-#pragma unroll
-            for (int n = 0; n < 5; ++n) {
-              f32x8 v = chunk_val(h + n);
-              const bf16x8 x = __builtin_bit_cast(bf16x8, raw[n]);
-#pragma unroll
-              for (int r = 0; r < 8; ++r) v.v[r] *= (float)x[r];
-              __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro, chunk_off(h + n, oA, oB, a.e.ldo) * 2u, 0, 0);
-            }
-          }
-        }
-      } else {  // EPI_SLAB_F32: split-K partial of the wgrad form, f32
-        float* slab = reinterpret_cast<float*>(a.e.out) + (size_t)tz * a.e.slab_stride;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (int)min((long)a.I * a.e.ldo * 4, 0x7FFFFFF0L), 0x00020000);
-        const unsigned oA = (unsigned)(rowA * a.e.ldo + colA), oB = (unsigned)(rowB * a.e.ldo + colB);
-#pragma unroll
-        for (int n = 0; n < C::NCHUNK; ++n) {
-          const f32x8 v = chunk_val(n);
-          const unsigned off = chunk_off(n, oA, oB, a.e.ldo) * 4u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.v[0], v.v[1], v.v[2], v.v[3]}), ro, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v.v[4], v.v[5], v.v[6], v.v[7]}), ro, off + 16u, 0, 0);
-        }
-      }
-      e1 += (C::DBG & 2) ? 1 : C::EPI_OPS;
-    }
+    e1 += epilogue(ti, tj, tz);
     if (!more) break;
     cv = nv; ti = n_ti; tj = n_tj; tz = n_tz;
     c_par ^= 1;
@@ -403,14 +561,18 @@ template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stre
   if (nblocks > 256) nblocks = 256;  // one persistent workgroup per CU
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);
     if (e != hipSuccess) {
       v4h_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, (size_t)C::LDS_BYTES, hipGetErrorString(e));
       return V4H_ERR_HIP;
     }
     attr_set = true;
   }
+#ifdef V4H_GEMM2_STAMPS
+  hipLaunchKernelGGL(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES + 2048, stream, a);
+#else
   hipLaunchKernelGGL(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES, stream, a);
+#endif
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;
 }
