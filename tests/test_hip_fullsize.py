@@ -1,7 +1,7 @@
 """-m gpu: BASELINE.json's full size (ds2 shape model, depth 6, B = 128) through size-independent properties, since the
 CPU oracle needs seconds per step there:
-  * batch independence: row b of forward(B = 128) equals forward of the sub-batch containing b (bitwise: the K-order of
-    every output element does not depend on the tile it falls in),
+  * batch independence: row b of forward(B = 128) equals forward of the sub-batch containing b (bitwise while one contraction kernel serves both
+    sizes: the K-order of every output element does not depend on the tile it falls in; to bf16 rounding across the two bf16 kernels),
   * linearity: grad of the batch-mean loss = mean of the grads of two half batches,
   * reproducibility: two backward passes give bit-identical weight gradients (split-K partial slabs, no float atomics),
   * and a few rows are still checked against the oracle directly.
@@ -13,6 +13,7 @@ import torch
 
 from oracle import vit_cfm_oracle as O
 from tests import hiputil as U
+from vit4hep_amd import _lib
 
 pytestmark = pytest.mark.gpu
 CFG = O.ds2(6)
@@ -36,12 +37,25 @@ def _grads(model, x, c, t, x0):
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_forward_is_batch_independent_and_matches_oracle_rows(mode):
     model, x, c, t, x0 = _setup(mode)
+    lib = _lib.load()
     with torch.no_grad():
         xt = (1 - t) * x0 + t * x
-        full = model.forward(xt, t.view(-1, 1), c)
-        for lo, hi in ((0, 8), (56, 72), (120, 128)):
-            part = model.forward(xt[lo:hi].contiguous(), t[lo:hi].view(-1, 1).contiguous(), c[lo:hi].contiguous())
-            assert torch.equal(part, full[lo:hi]), (mode, lo)
+        # Bit-identical rows whatever the batch, as long as one contraction kernel serves both sizes (f32 mode always; bf16 with the ring kernel off).
+        # The default bf16 dispatch gives token counts >= 2048 to the ring kernel, whose accumulators start from the bias instead of adding it at the
+        # end: the same sums in another rounding order, so there the rows agree to bf16 rounding.
+        for pinned in (True, False):
+            if pinned:
+                lib.v4h_debug_set_gemm_cfg(0, 1000)
+            try:
+                full = model.forward(xt, t.view(-1, 1), c)
+                for lo, hi in ((0, 8), (56, 72), (120, 128)):
+                    part = model.forward(xt[lo:hi].contiguous(), t[lo:hi].view(-1, 1).contiguous(), c[lo:hi].contiguous())
+                    if pinned or mode == "f32":
+                        assert torch.equal(part, full[lo:hi]), (mode, lo)
+                    else:
+                        assert U.rel_err(part, full[lo:hi]) < 1e-2, (mode, lo)
+            finally:
+                lib.v4h_debug_set_gemm_cfg(0, -1)
     rows = slice(60, 62)
     ref = O.cfm_forward(O.golden_fill(CFG), xt[rows].cpu(), t[rows].view(-1, 1).cpu(), c[rows].cpu(), CFG)
     assert U.rel_err(full[rows], ref) < (1e-4 if mode == "f32" else 3e-2)

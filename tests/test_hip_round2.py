@@ -87,12 +87,24 @@ def _grads(model, x, c, t, x0):
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_ds3_b64_forward_is_batch_independent_and_matches_oracle_rows(mode):
     model, x, c, t, x0 = _setup3(mode)
+    lib = _lib.load()
     with torch.no_grad():
         xt = (1 - t) * x0 + t * x
-        full = model.forward(xt, t.view(-1, 1), c)
-        for lo, hi in ((0, 4), (29, 35), (60, 64)):
-            part = model.forward(xt[lo:hi].contiguous(), t[lo:hi].view(-1, 1).contiguous(), c[lo:hi].contiguous())
-            assert torch.equal(part, full[lo:hi]), (mode, lo)
+        # bitwise while one contraction kernel serves both batch sizes (f32; bf16 with the ring kernel off); to bf16 rounding across the two bf16
+        # kernels (the ring kernel's accumulators start from the bias): tests/test_hip_fullsize.py
+        for pinned in (True, False):
+            if pinned:
+                lib.v4h_debug_set_gemm_cfg(0, 1000)
+            try:
+                full = model.forward(xt, t.view(-1, 1), c)
+                for lo, hi in ((0, 4), (29, 35), (60, 64)):
+                    part = model.forward(xt[lo:hi].contiguous(), t[lo:hi].view(-1, 1).contiguous(), c[lo:hi].contiguous())
+                    if pinned or mode == "f32":
+                        assert torch.equal(part, full[lo:hi]), (mode, lo)
+                    else:
+                        assert U.rel_err(part, full[lo:hi]) < 1e-2, (mode, lo)
+            finally:
+                lib.v4h_debug_set_gemm_cfg(0, -1)
     rows = slice(31, 32)
     ref = O.cfm_forward(O.golden_fill(CFG3), xt[rows].cpu(), t[rows].view(-1, 1).cpu(), c[rows].cpu(), CFG3)
     assert U.rel_err(full[rows], ref) < (1e-4 if mode == "f32" else 3e-2)

@@ -71,6 +71,7 @@ struct GemmArgs {
   int I, J, K;
   int klen;          // K range per split (multiple of BK)
   int stagger_sleeps;  // tuning: s_sleep(127) count (8128 cycles each) for the second half of a persistent grid
+  int sched_flags;   // ring kernel, ping-pong schedule (set by its launcher from V4H_PP_FLAGS): bit 0 = the two halves write a finished tile in the same slot
   int nti, ntj, nz;  // tiles along i, along j, K splits (filled by the launcher; 1-D grid, XCD-aware decode in the kernel)
   float* colsum;     // optional: colsum[i] += sum_k P[i][k]   (f32 atomics; only j-tile 0 contributes)
   EpiArgs e;

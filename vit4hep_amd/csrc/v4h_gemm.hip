@@ -97,14 +97,20 @@ template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream
 // (the sampler at the reference's batch of 256: 34560 rows = 135 tiles; 1210 -> 1270 showers/s, profiles/r02_ab_in_context.txt); 0 = never;
 // 1 = wherever eligible (the update step at bs = 128, 67.5 row tiles: 195 vs 208 steps/s - not the default); 2.. = ablation builds (tools/gemm2_bench.py).
 int g_v2 = env_flag("V4H_GEMM2", -1);
+// Which contractions take the ring kernel's ping-pong schedule when V4H_GEMM2 is -1 (bits: 1 forward plain store, 2 forward GELU, 4 dgrad plain store,
+// 8 dgrad DGELU, 16 split-K weight-gradient slabs), wherever the shape is eligible.
+int g_pp = env_flag("V4H_GEMM2_PP", 21);
 inline bool v2_eligible(const GemmArgs& a, int klen) {
   return a.I >= 2048 && a.J % 160 == 0 && klen >= 192 && a.e.ldo % 8 == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 4 < 0x7FFFFFF0L;
 }
 inline bool v2_ok(const GemmArgs& a, int klen) { return g_v2 > 0 && v2_eligible(a, klen); }
 inline bool v2_auto_fwd(const GemmArgs& a) { return g_v2 < 0 && a.I % 256 == 0 && a.I >= 8192 && v2_eligible(a, a.K); }
+inline bool pp_auto(const GemmArgs& a, int klen, int bit) { return g_v2 < 0 && (g_pp & bit) && v2_eligible(a, klen); }
 
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (epi == EPI_STORE && pp_auto(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_fwd/store");
+    if (epi == EPI_GELU && pp_auto(a, a.K, 2) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
     if (v2_ok(a, a.K) || v2_auto_fwd(a)) {
       if (epi == EPI_STORE && g_v2 == 2) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1>>(a, 1, s, "gemm2_fwd/store/dbg1");
       if (epi == EPI_STORE && g_v2 == 3) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2>>(a, 1, s, "gemm2_fwd/store/dbg2");
@@ -144,6 +150,8 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
 
 template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (epi == EPI_STORE && pp_auto(a, a.K, 4)) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/store");
+    if (epi == EPI_DGELU && pp_auto(a, a.K, 8) && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/dgelu");
     if (v2_ok(a, a.K)) {
       if (epi == EPI_STORE && g_v2 == 8) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/store");
       if (epi == EPI_DGELU && g_v2 == 8 && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false, 0, true>>(a, 1, s, "gemm2pp_dgrad/dgelu");
@@ -181,8 +189,8 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + bk - 1) / bk * bk;
   *nz_out = (a.K + klen - 1) / klen;
-  if (m == MODE_BF16 && g_v2 > 0 && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
-    return g_v2 == 8 ? v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true, 0, true>>(a, splitk, s, "gemm2pp_wgrad/slab")
+  if (m == MODE_BF16 && (g_v2 > 0 || (g_v2 < 0 && (g_pp & 16))) && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
+    return (g_v2 == 8 || g_v2 < 0) ? v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true, 0, true>>(a, splitk, s, "gemm2pp_wgrad/slab")
                      : v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the
   // split the runtime uses); 96 x 160 is 2-4 % ahead on three of the four block shapes

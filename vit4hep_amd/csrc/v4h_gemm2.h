@@ -273,6 +273,10 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
   // per row and instruction; n >= 8: the odd fifth column tile, paired over the row strips x = 2 (n - 8) and x + 1.  J is a whole number of
   // 160-column tiles (launcher), rows beyond I fall outside the buffer and are dropped by its bounds check: no predicate anywhere.
   auto epilogue = [&](int ti, int tj, int tz) -> int {
+    // (the lane coordinates are laundered through an empty asm: the epilogue has three call sites in the ping-pong schedule and runs once per tile, so
+    //  its per-lane offsets are to be recomputed at each, not hoisted out of the K loop into ten registers that live across it)
+    int c = lane & 15, g = lane >> 4;
+    asm volatile("" : "+v"(c), "+v"(g));
     const int ge = g & 1, gh = g >> 1;
     const int rowA = ti * C::BI + wi * C::WTI + c, colA = tj * C::BJ + wj * C::WTJ + 16 * ge + 8 * gh;
     const int rowB = rowA + 16 * ge, colB = tj * C::BJ + wj * C::WTJ + 64 + 8 * gh;
@@ -367,6 +371,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
   if constexpr (C::PP) {
     static_assert(!(C::DBG & ~3), "the other ablation builds belong to the lock-step schedule");
     const int half = wave >> 2;
+    const bool seam_overlap = (a.sched_flags & 1) != 0;
     auto slot_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
@@ -407,7 +412,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
         };
         if (C::EPI != EPI_DGELU) p_part();  // (the DGELU epilogue loads: its waits would also wait for a DMA issued in front of it)
         if (t == 0) {
-          if (have_prev) {
+          if (have_prev && (half == 0 || !seam_overlap)) {  // (half 1 wrote its part of the previous tile at the end of its last matrix slot - in this same slot)
             const int n = epilogue(p_ti, p_tj, p_tz);
             yo += n;
             yn += n;
@@ -443,6 +448,13 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
         advance();  // (scalar and vector ALU work only: it issues between the MFMAs)
         mfmas(pB, qB, 0, C::TI);
         V4H_G2_STAMP(4);
+        if (half == 1 && t == nt - 1 && seam_overlap) {
+          // Tile seam: half 0 is now in the load slot that starts with ITS epilogue of this tile; half 1 runs its own right here, beside it, instead
+          // of in its next load slot - the two epilogues (about 2500 clocks each) overlap instead of following each other.
+          const int n = epilogue(ti, tj, tz);
+          yo += n;
+          yn += n;
+        }
         if (half == 0) {
           wait_vmcnt64(sgpr(yo));
           yo = yn;
@@ -461,7 +473,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       c_par ^= 1;
     }
     if (half == 0) slot_barrier();  // the slot in which half 1 multiplies its last stage
-    epilogue(p_ti, p_tj, p_tz);
+    if (half == 0 || !seam_overlap) epilogue(p_ti, p_tj, p_tz);
 #ifdef V4H_GEMM2_STAMPS
     __builtin_amdgcn_s_waitcnt(0xC07F);
     v4h_gemm2_stamp_buf[(blockIdx.x * 8 + wave) * G2_ST_N * G2_ST_K + lane] = reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[wave * G2_ST_N * G2_ST_K + lane];
@@ -559,6 +571,10 @@ template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stre
   a.ntj = (a.J + C::BJ - 1) / C::BJ;
   long nblocks = a.nz == 1 ? (a.nti < 8 ? (long)a.nti * a.ntj : (long)((a.nti + 7) / 8) * 8 * a.ntj) : (long)a.nti * a.ntj * a.nz;
   if (nblocks > 256) nblocks = 256;  // one persistent workgroup per CU
+  // V4H_PP_FLAGS bit 0: both halves of the ping-pong schedule write a finished tile in the same slot.  Isolated it is neutral, inside the update step it
+  // LOSES (224.6 vs 226.4 steps/s, interleaved on one box): two store bursts at once are worse than two in a row.  Default off.
+  static const int pp_flags = [] { const char* e = getenv("V4H_PP_FLAGS"); return e ? atoi(e) : 0; }();
+  a.sched_flags = pp_flags;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);
