@@ -198,7 +198,7 @@ def op_rates(mode, BT, device, reps=20):
                                                                 "frac_of_spec_peak": round(fl / us / 1e6 / (BF16_DENSE_PEAK_TFLOPS if mode == "bf16" else F32_MFMA_PEAK_TFLOPS), 4)}
     # the dominant kernel of the step: the split-K weight gradients (dW = dY^T X over the tokens; partial slabs + ordered reduce, bias-gradient column sums on)
     for name, (I, J) in {"wgrad qkv 1440x480": (1440, 480), "wgrad proj 480x480": (480, 480), "wgrad fc1 1920x480": (1920, 480), "wgrad fc2 480x1920": (480, 1920)}.items():
-        sk = 8 if I * J >= 40 * 96 * 160 else 16
+        sk = int(lib.v4h_op_gemm_wgrad_splitk(_lib.MODES[mode], I, J, BT))  # the split the backward pass itself uses
         P = torch.randn((BT, I), device=device).to(dt)
         Q = torch.randn((BT, J), device=device).to(dt)
         o = torch.zeros((I, J), device=device)

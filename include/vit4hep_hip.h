@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 5
+#define V4H_ABI_VERSION 6
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -203,6 +203,8 @@ int32_t v4h_op_gemm(int32_t mode, const void* d_P, int32_t ldp, int32_t p_kstrid
  * d_colsum[i] += sum_k P[k][i] (the bias gradient).  nn.Linear wgrad, reference nn/vit.py:416,420 + timm Mlp :317-322. */
 int32_t v4h_op_gemm_wgrad_slab(int32_t mode, const void* d_P, int32_t ldp, const void* d_Q, int32_t ldq, float* d_slab, float* d_out, int32_t I, int32_t J,
                                int32_t K, int32_t splitk, float* d_colsum, void* stream);
+/* The number of K splits the backward pass itself uses for a weight gradient of this shape (a function of the kernel it dispatches to and the 256 CUs). */
+int32_t v4h_op_gemm_wgrad_splitk(int32_t mode, int32_t I, int32_t J, int32_t K);
 /* softmax(q k^T / sqrt(dh)) v on token-major qkv (B*T, 3*H*dh) -> o (B*T, H*dh), lse (B,H,T)   nn/vit.py:425-451 */
 int32_t v4h_op_attention_fwd(int32_t mode, const void* d_qkv, void* d_o, float* d_lse, int32_t B, int32_t T, int32_t H, int32_t dh, void* stream);
 int32_t v4h_op_attention_bwd(int32_t mode, const void* d_qkv, const void* d_o, const void* d_do, const float* d_lse, float* d_delta, void* d_dqkv,

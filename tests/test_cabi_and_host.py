@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_plan_inventory_matches_reference_state_dict():

@@ -66,7 +66,9 @@ def make(name, I, J, K, pks, qks, splitk=1):
 shapes = [("fwd qkv", BT, 3 * D, D, 0, 0, 1), ("fwd proj", BT, D, D, 0, 0, 1), ("fwd fc1", BT, M, D, 0, 0, 1), ("fwd fc2", BT, D, M, 0, 0, 1),
           ("dgrad qkv", BT, D, 3 * D, 0, 1, 1), ("dgrad proj", BT, D, D, 0, 1, 1), ("dgrad fc1", BT, D, M, 0, 1, 1), ("dgrad fc2", BT, M, D, 0, 1, 1),
           ("wgrad qkv", 3 * D, D, BT, 1, 1, 8), ("wgrad proj", D, D, BT, 1, 1, 8), ("wgrad fc1", M, D, BT, 1, 1, 8), ("wgrad fc2", D, M, BT, 1, 1, 8),
-          ("wgrad fc1 s4", M, D, BT, 1, 1, 4), ("wgrad qkv s14", 3 * D, D, BT, 1, 1, 14)]
+          ("wgrad fc1 s4", M, D, BT, 1, 1, 4), ("wgrad qkv s14", 3 * D, D, BT, 1, 1, 14), ("wgrad qkv s16", 3 * D, D, BT, 1, 1, 16), ("wgrad fc1 s10", M, D, BT, 1, 1, 10),
+          ("wgrad fc2 s10", D, M, BT, 1, 1, 10), ("wgrad fc1 s16", M, D, BT, 1, 1, 16), ("wgrad proj s16", D, D, BT, 1, 1, 16), ("wgrad proj s24", D, D, BT, 1, 1, 24),
+          ("wgrad proj s32", D, D, BT, 1, 1, 32), ("wgrad proj s40", D, D, BT, 1, 1, 40)]
 only = os.environ.get("ONLY")
 for nm, I, J, K, pks, qks, sk in shapes:
     if only and only not in nm:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -81,6 +81,7 @@ SIGNATURES = {
     "v4h_rk4_combine": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "v4h_op_gemm": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "v4h_op_gemm_wgrad_slab": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "v4h_op_gemm_wgrad_splitk": (_i32, [_i32, _i32, _i32, _i32]),
     "v4h_op_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "v4h_op_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "v4h_op_ln_modulate_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

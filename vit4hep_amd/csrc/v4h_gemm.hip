@@ -109,8 +109,9 @@ inline bool pp_auto(const GemmArgs& a, int klen, int bit) { return g_v2 < 0 && (
 
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    if (epi == EPI_STORE && pp_auto(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_fwd/store");
-    if (epi == EPI_GELU && pp_auto(a, a.K, 2) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
+    // (forward at a whole number of 256-row tiles - the sampler at its batch of 256 - stays on the lock-step schedule: 1287 vs 1263 showers/s)
+    if (epi == EPI_STORE && pp_auto(a, a.K, 1) && !v2_auto_fwd(a)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_fwd/store");
+    if (epi == EPI_GELU && pp_auto(a, a.K, 2) && !v2_auto_fwd(a) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
     if (v2_ok(a, a.K) || v2_auto_fwd(a)) {
       if (epi == EPI_STORE && g_v2 == 2) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1>>(a, 1, s, "gemm2_fwd/store/dbg1");
       if (epi == EPI_STORE && g_v2 == 3) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2>>(a, 1, s, "gemm2_fwd/store/dbg2");
@@ -181,6 +182,33 @@ int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk) { 
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s) {
   return m == MODE_BF16 ? run_wgrad_cfg<bf16>(a, splitk, s) : run_wgrad_cfg<float>(a, splitk, s);
 }
+// Does the split-K weight gradient of this shape take the ring kernel (ping-pong schedule)?  256 x 160 tiles, one workgroup per CU: it needs at least a
+// dozen tiles to be worth it (attn.proj, 480 x 480 = 6 tiles, stays on the two-workgroup kernel: 32.8 vs 34.5 us at 16 splits).
+static bool wgrad_ring_shape(Mode m, int I, int J) {
+  const int tiles = ((I + 255) / 256) * (J / 160);
+  return m == MODE_BF16 && I >= 160 && J % 160 == 0 && I % 8 == 0 && (g_v2 > 0 || (g_v2 < 0 && (g_pp & 16) && tiles >= 12));
+}
+// K splits of a weight gradient: a multiple of 8 (one or more K slices per XCD).  Ring kernel (256 x 160 tiles): 8 - 144 to 192 workgroups for the block's
+// shapes.  Alone, one workgroup per CU is faster (18 tiles x 14 splits: 45.2 vs 52.9 us for attn.qkv, 24 x 10: 49.8 vs 53.8 for mlp.fc1, reduction included -
+// tools/gemm2_bench.py); inside the backward pass it LOSES (213.2 vs 217.1 steps/s, interleaved on one box; 192 workgroups 214.8, 160: 216.2): the weight
+// gradients run on the side stream beside the dgrad chain, a 160 KB-LDS workgroup owns its CU, and the CUs it leaves free are where dgrad runs meanwhile.
+// V4H_WGRAD_WGS = n > 0: as many splits as give about n workgroups; -n: n splits.
+int gemm_wgrad_splitk(Mode m, int I, int J, int K) {
+  int sk;
+  if (wgrad_ring_shape(m, I, J) && g_v2 < 0) {
+    static const int target = env_flag("V4H_WGRAD_WGS", -8);
+    sk = target / (((I + 255) / 256) * (J / 160));
+    if (sk > 16) sk = 16;
+    if (target < 0) sk = -target;
+  } else {
+    const int tiles = ((I + 95) / 96) * ((J + 159) / 160);
+    sk = tiles >= 40 ? 8 : 16;
+    if (tiles < 8) sk = 32;
+  }
+  const int maxk = K / 128;  // at least two K-steps of 64 per split
+  if (sk > maxk) sk = maxk;
+  return sk < 1 ? 1 : sk;
+}
 // split-K partials into a slab [nz][I][J] with plain stores; returns the number of splits actually used in *nz_out
 int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz_out, hipStream_t s) {
   GemmArgs a = a0;
@@ -189,7 +217,7 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
   int klen = (a.K + splitk - 1) / splitk;
   klen = (klen + bk - 1) / bk * bk;
   *nz_out = (a.K + klen - 1) / klen;
-  if (m == MODE_BF16 && (g_v2 > 0 || (g_v2 < 0 && (g_pp & 16))) && a.I >= 160 && a.J % 160 == 0 && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192 && a.I % 8 == 0)
+  if (wgrad_ring_shape(m, a.I, a.J) && klen >= 192 && a.K - (*nz_out - 1) * klen >= 192)
     return (g_v2 == 8 || g_v2 < 0) ? v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true, 0, true>>(a, splitk, s, "gemm2pp_wgrad/slab")
                      : v4h_gemm2_launch<Gemm2Cfg<true, true, EPI_SLAB_F32, true>>(a, splitk, s, "gemm2_wgrad/slab");
   // tile shape: a plateau (tools/wgrad_tile_bench.py, profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the

@@ -12,6 +12,7 @@ inline size_t esize(Mode m) { return m == MODE_BF16 ? 2 : 4; }
 int gemm_fwd(Mode m, int epi, const GemmArgs& a, hipStream_t s);              // P contig, Q contig
 int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk = 1);  // P contig, Q K-strided (split-K only with EPI_ATOMIC_F32)
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s);         // both K-strided, f32 atomics (+ colsum)
+int gemm_wgrad_splitk(Mode m, int I, int J, int K);  // the split count the runtime uses for a weight gradient of this shape
 int gemm_wgrad_slab(Mode m, const GemmArgs& a, int splitk, float* slab, int* nz_out, hipStream_t s);  // partials [nz][I][J], plain stores
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s);  // out[k] += sum_z slab[z*n + k]
 

@@ -255,12 +255,11 @@ struct WS {
   size_t total;
 };
 
-// scratch for the split-K partials of the largest weight gradient (fc1 / fc2: 8 splits; attn.proj: 16)
+// scratch for the split-K partials of the largest weight gradient: at most 16 splits (gemm_wgrad_splitk) of the fc1 / fc2 or qkv shape
 static size_t slab_bytes(const v4h_plan& p) {
   const size_t D = p.D, M = p.M;
-  size_t mx = 8 * D * M;
-  if (8 * 3 * D * D > mx) mx = 8 * 3 * D * D;
-  if (16 * D * D > mx) mx = 16 * D * D;
+  size_t mx = 16 * D * M;
+  if (16 * 3 * D * D > mx) mx = 16 * 3 * D * D;
   return mx * 4;
 }
 
@@ -418,21 +417,11 @@ static GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int
   return a;
 }
 
-// K splits of a wgrad: a multiple of 8 (one or more per XCD) giving about one workgroup per CU; every split costs one
-// f32-atomic pass over the output (~1.3 TB/s chip-wide), so no more than that.
-static int wgrad_splitk(int I, int J, int K) {
-  const int tiles = ((I + 95) / 96) * ((J + 159) / 160);  // 96 x 160 tiles (v4h_gemm.hip: gemm_wgrad_slab)
-  int sk = tiles >= 40 ? 8 : 16;
-  if (tiles < 8) sk = 32;
-  const int maxk = K / 128;  // at least 4 K-steps per split
-  if (sk > maxk) sk = maxk;
-  return sk < 1 ? 1 : sk;
-}
 // dW[I][J] += dY^T X  (+ db[I] += column sums of dY)
 static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db, hipStream_t s = nullptr) {
   GemmArgs a = gargs(dY, ld_dy, X, ld_x, I, J, K);
   a.e.out = dW; a.e.ldo = ldo; a.colsum = db;
-  const int sk = wgrad_splitk(I, J, K);
+  const int sk = gemm_wgrad_splitk(c.p.mode, I, J, K);
   hipStream_t st = s ? s : c.s;
   // Split-K partial sums: plain coalesced stores into a slab + one reduce pass instead of sk-fold f32 atomics (which run
   // at ~1.3 TB/s at the memory side): faster, and the weight gradient is bitwise reproducible.
@@ -907,6 +896,10 @@ extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t
   }
   v4h_set_error("op_gemm: layout (P K-strided, Q K-contiguous) is not used on the path and not built");
   return V4H_ERR_UNSUPPORTED;
+}
+extern "C" int32_t v4h_op_gemm_wgrad_splitk(int32_t mode, int32_t I, int32_t J, int32_t K) {
+  if ((mode != 0 && mode != 1) || I <= 0 || J <= 0 || K <= 0) return 1;
+  return gemm_wgrad_splitk((Mode)mode, I, J, K);
 }
 extern "C" int32_t v4h_op_gemm_wgrad_slab(int32_t mode, const void* P, int32_t ldp, const void* Q, int32_t ldq, float* slab, float* out, int32_t I, int32_t J, int32_t K,
                                           int32_t splitk, float* colsum, void* s) {
