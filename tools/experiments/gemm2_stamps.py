@@ -43,6 +43,6 @@ for half in (0, 1):
     print(f"half {half}: median clocks per stage (t = stage within its tile; {nt} stages per tile), over all workgroups and the half's 4 waves")
     for n in range(NST - 1):
         dma = dif(w[..., 6], w[..., 0])[:, :, n]
-        extra = f" [DMA issue {int(np.median(dma))}]" if w[..., 6].any() else ""
+        extra = f" [DMA issue {int(np.median(dma))}]" if os.environ.get("DMA_FIRST") else ""  # (stamp 6 exists only in a -DV4H_G2_DMA_FIRST build)
         print(f"  stage {FIRST + n} (t={(FIRST + n) % nt}):{extra} " + "; ".join(f"{nm.split(' (')[0]} {int(np.median(x[:, :, n]))}" for nm, x in zip(names, d)) + f"  | stage total {int(np.median(dif(nxt0, w[..., 0])[:, :, n]))}")
 lib.v4h_debug_set_gemm_cfg(0, -1)

@@ -192,8 +192,8 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
     }
     return sgpr(n);
   };
-  auto advance = [&]() {
-    if (!r_valid) return;
+  auto advance_walk = [&]() -> bool {  // true: a new tile starts, tile_setup() is due
+    if (!r_valid) return false;
     ++r_count;
     r_slot = r_slot == C::NS - 1 ? 0 : r_slot + 1;
     if (++r_t == r_nt) {
@@ -201,12 +201,13 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       r_par ^= 1;
       rv += gridDim.x;
       r_valid = decode(rv, r_ti, r_tj, r_tz);
-      if (r_valid) tile_setup();
+      return r_valid;
     }
+    return false;
   };
   auto request = [&]() -> int {
     const int n = issue();
-    advance();
+    if (advance_walk()) tile_setup();
     return n;
   };
 
@@ -445,7 +446,8 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
           if (++cs_phase == cs_period) cs_phase = 0;
         }
         mfmas(pA, qA, 0, C::TI);
-        advance();  // (scalar and vector ALU work only: it issues between the MFMAs)
+        if (advance_walk()) tile_setup();  // (ALU work only.  Weaving it between the MFMAs of the second group with sched_group_barrier changed nothing
+                                           //  measurable and cost 45 registers.)
         mfmas(pB, qB, 0, C::TI);
         V4H_G2_STAMP(4);
         if (half == 1 && t == nt - 1 && seam_overlap) {
