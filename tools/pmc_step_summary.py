@@ -27,6 +27,12 @@ def _short_gemm(n):
         epis = ["STORE", "STORE_F32", "SILU", "COND_SUM", "EMBED", "GATE_RESID", "GELU", "DGELU", "DSILU", "ATOMIC_F32", "ACCUM_F32", "UNPATCH", "SLAB_F32", "RELU", "ROWADD_SILU"]
         lay = {("0", "0"): "fwd", ("0", "1"): "dgrad", ("1", "1"): "wgrad"}[(pks, qks)]
         return f"gemm<{'bf16' if t == 'DF16b' else 'f32'},{lay},{bi}x{bj}x{bk},{epis[int(epi)]}{',colsum' if cs == '1' else ''}>"
+    m = re.match(r"(?:void )?v4h_gemm2_kernel<Gemm2Cfg<(true|false), (true|false), (\d+), (true|false), (\d+)(?:, (true|false))? ?> ?>", n)
+    if m:  # the 256 x 160 ring kernel (v4h_gemm2.h)
+        pks, qks, epi, cs, dbg, pp = m.groups()
+        epis = ["STORE", "STORE_F32", "SILU", "COND_SUM", "EMBED", "GATE_RESID", "GELU", "DGELU", "DSILU", "ATOMIC_F32", "ACCUM_F32", "UNPATCH", "SLAB_F32", "RELU", "ROWADD_SILU"]
+        lay = {("false", "false"): "fwd", ("false", "true"): "dgrad", ("true", "true"): "wgrad"}[(pks, qks)]
+        return f"gemm2<bf16,{lay},256x160x64,{epis[int(epi)]}{',colsum' if cs == 'true' else ''},{'ping-pong' if pp == 'true' else 'lock-step'}>"
     m = re.match(r"_ZN(?:3v4h)?12_GLOBAL__N_1(\d+)([A-Za-z_0-9]+)", n)
     if m:
         return m.group(2)[:int(m.group(1))]
