@@ -83,7 +83,7 @@ static int side_init(const v4h_plan& p) {
   int least = 0, greatest = 0;
   hipError_t se;
   if ((!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-    se = hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, greatest);
+    se = hipStreamCreateWithPriority(&p.side, hipStreamNonBlocking, (pe && pe[0] == 'l') ? least : greatest);  // V4H_SIDE_PRIORITY=low: the other non-default class
   else
     se = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
   if (se != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
