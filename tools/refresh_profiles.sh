@@ -30,7 +30,7 @@ V4H_FORCE_COLLECTIVES=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline
 ABL=1 python3 tools/gemm2_bench.py > $out/gemm2_ablation.txt 2>&1 || true
 # in-context A/B of the alternatives that are kept behind switches (interleaved, same box)
 for r in 1 2; do
-  for v in "V4H_GEMM2=-1" "V4H_GEMM2=0" "V4H_GEMM2_PP=0" "V4H_GEMM2_PP=31" "V4H_GEMM2_PP=5" "V4H_PP_FLAGS=1" "V4H_WGRAD_WGS=256" "V4H_GEMM_STRIPS=0" "V4H_LN_RESID=0"; do
+  for v in "V4H_GEMM2=-1" "V4H_GEMM2=0" "V4H_GEMM2_PP=0" "V4H_GEMM2_PP=63" "V4H_GEMM2_PP=37" "V4H_PP_FLAGS=2" "V4H_FWD_LOCKSTEP=1" "V4H_WGRAD_WGS=256" "V4H_GEMM_STRIPS=0" "V4H_LN_RESID=0"; do
     echo -n "$v  " >> $out/ab_in_context.txt
     env $v python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-op-rates 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], 'steps/s', r['ms_per_step'], 'ms', r['sampling']['rk4']['showers_per_s'], 'showers/s (RK4)')" >> $out/ab_in_context.txt
   done

@@ -97,21 +97,23 @@ template <typename T> int run_wgrad_cfg(const GemmArgs& a, int splitk, hipStream
 // (the sampler at the reference's batch of 256: 34560 rows = 135 tiles; 1210 -> 1270 showers/s, profiles/r02_ab_in_context.txt); 0 = never;
 // 1 = wherever eligible (the update step at bs = 128, 67.5 row tiles: 195 vs 208 steps/s - not the default); 2.. = ablation builds (tools/gemm2_bench.py).
 int g_v2 = env_flag("V4H_GEMM2", -1);
-// Which contractions take the ring kernel's ping-pong schedule when V4H_GEMM2 is -1 (bits: 1 forward plain store, 2 forward GELU, 4 dgrad plain store,
-// 8 dgrad DGELU, 16 split-K weight-gradient slabs), wherever the shape is eligible.
-int g_pp = env_flag("V4H_GEMM2_PP", 21);
+// Which contractions take the ring kernel's ping-pong schedule when V4H_GEMM2 is -1 (bits: 1 forward plain store, 2 forward GELU of the update step - two
+// outputs, 4 dgrad plain store, 8 dgrad DGELU, 16 split-K weight-gradient slabs, 32 forward GELU without the saved derivative - inference), wherever the shape
+// is eligible.  Default: everything but the two heavy epilogues of the update step, which have nothing to hide behind in that schedule.
+int g_pp = env_flag("V4H_GEMM2_PP", 53);
 inline bool v2_eligible(const GemmArgs& a, int klen) {
   return a.I >= 2048 && a.J % 160 == 0 && klen >= 192 && a.e.ldo % 8 == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 4 < 0x7FFFFFF0L;
 }
 inline bool v2_ok(const GemmArgs& a, int klen) { return g_v2 > 0 && v2_eligible(a, klen); }
-inline bool v2_auto_fwd(const GemmArgs& a) { return g_v2 < 0 && a.I % 256 == 0 && a.I >= 8192 && v2_eligible(a, a.K); }
+int g_fwd_lockstep = env_flag("V4H_FWD_LOCKSTEP", 0);  // 1: forward at whole 256-row tiles (the sampler at its batch of 256) on the LOCK-STEP schedule of the ring kernel
+                                                       // (the default until the ping-pong schedule dropped its mid-stage barrier: 1292 vs 1342 showers/s)
+inline bool v2_auto_fwd(const GemmArgs& a) { return g_v2 < 0 && g_fwd_lockstep && a.I % 256 == 0 && a.I >= 8192 && v2_eligible(a, a.K); }
 inline bool pp_auto(const GemmArgs& a, int klen, int bit) { return g_v2 < 0 && (g_pp & bit) && v2_eligible(a, klen); }
 
 template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    // (forward at a whole number of 256-row tiles - the sampler at its batch of 256 - stays on the lock-step schedule: 1287 vs 1263 showers/s)
     if (epi == EPI_STORE && pp_auto(a, a.K, 1) && !v2_auto_fwd(a)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 0, true>>(a, 1, s, "gemm2pp_fwd/store");
-    if (epi == EPI_GELU && pp_auto(a, a.K, 2) && !v2_auto_fwd(a) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
+    if (epi == EPI_GELU && pp_auto(a, a.K, a.e.out != nullptr ? 2 : 32) && !v2_auto_fwd(a) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false, 0, true>>(a, 1, s, "gemm2pp_fwd/gelu");
     if (v2_ok(a, a.K) || v2_auto_fwd(a)) {
       if (epi == EPI_STORE && g_v2 == 2) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 1>>(a, 1, s, "gemm2_fwd/store/dbg1");
       if (epi == EPI_STORE && g_v2 == 3) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false, 2>>(a, 1, s, "gemm2_fwd/store/dbg2");
