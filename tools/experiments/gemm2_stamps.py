@@ -1,7 +1,7 @@
 """Slot timeline of the ping-pong ring contraction (diagnostic build: V4H_EXTRA_FLAGS=-DV4H_GEMM2_STAMPS python -m vit4hep_amd.build --force).
 Stamps (shader clock) per wave and stage: 0 load slot starts, 1 fragments in registers / DMA share and (at a seam) epilogue issued, 2 after the counted vmcnt wait
 (half 1), 3 after the barrier = matrix slot starts, 4 MFMAs issued, 5 after the counted vmcnt wait (half 0); the next stage's 0 is after the second barrier.
-usage (GPU box): python tools/experiments/gemm2_stamps.py [fc1|qkv|fc2|proj] [ver]"""
+usage (GPU box): python tools/experiments/gemm2_stamps.py [fc1|qkv|fc2|proj|wgrad_qkv|wgrad_fc1|wgrad_fc2] [ver]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -13,25 +13,39 @@ lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 dev = "cuda:0"
 BT = 17280
-J, K = {"fc1": (1920, 480), "qkv": (1440, 480), "fc2": (480, 1920), "proj": (480, 480)}[which]
 dt = torch.bfloat16
-P = torch.randn((BT, K), device=dev).to(dt)
-Q = torch.randn((J, K), device=dev).to(dt)
-bias = torch.randn(J, device=dev)
-out = torch.empty((BT, J), device=dev, dtype=dt)
 s = _lib.stream_ptr(dev)
 lib.v4h_debug_set_gemm_cfg(0, 1000 * ver)
-args = (_lib.MODES["bf16"], _lib.ptr(P), K, 0, _lib.ptr(Q), K, 0, _lib.ptr(bias), _lib.ptr(out), J, 0, BT, J, K, 1, None, s)
+if which.startswith("wgrad"):  # weight gradient of the block's qkv / fc1 / fc2 Linear: both operands token-major, split-K slabs
+    I, J = {"wgrad_qkv": (1440, 480), "wgrad_fc1": (1920, 480), "wgrad_fc2": (480, 1920)}[which]
+    K = BT // 8  # (K of one split, for the stage count printed below)
+    P = torch.randn((BT, I), device=dev).to(dt)
+    Q = torch.randn((BT, J), device=dev).to(dt)
+    out = torch.zeros((I, J), device=dev)
+    slab = torch.empty((8, I, J), device=dev)
+    cs = torch.zeros(I, device=dev)
+    args = (_lib.MODES["bf16"], _lib.ptr(P), I, _lib.ptr(Q), J, _lib.ptr(slab), _lib.ptr(out), I, J, BT, 8, _lib.ptr(cs), s)
+    call = lib.v4h_op_gemm_wgrad_slab
+else:
+    J, K = {"fc1": (1920, 480), "qkv": (1440, 480), "fc2": (480, 1920), "proj": (480, 480)}[which]
+    P = torch.randn((BT, K), device=dev).to(dt)
+    Q = torch.randn((J, K), device=dev).to(dt)
+    bias = torch.randn(J, device=dev)
+    out = torch.empty((BT, J), device=dev, dtype=dt)
+    args = (_lib.MODES["bf16"], _lib.ptr(P), K, 0, _lib.ptr(Q), K, 0, _lib.ptr(bias), _lib.ptr(out), J, 0, BT, J, K, 1, None, s)
+    call = lib.v4h_op_gemm
 for _ in range(5):
-    _lib.check(lib.v4h_op_gemm(*args))
+    _lib.check(call(*args))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); _lib.check(lib.v4h_op_gemm(*args)); e1.record(); torch.cuda.synchronize()
+e0.record(); _lib.check(call(*args)); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
 FIRST, NST, NK = 3, 8, 8
 buf = np.zeros(256 * 8 * NST * NK, dtype=np.uint32)
 assert raw.v4h_debug_gemm2_stamps(buf.ctypes.data_as(C.c_void_p)) == 0
 st = buf.reshape(256, 8, NST, NK)
+if which.startswith("wgrad"):
+    st = st[:((I + 255) // 256) * (J // 160) * 8]  # the workgroups this launch had (the rest of the buffer is from earlier launches)
 print(f"{which}: one call {us:.1f} us (stamped build)")
 nt = (K + 63) // 64
 names = ["load-slot work (frag reads, DMA issue, seam: epilogue)", "vmcnt wait (half 1)", "barrier wait", "MFMA issue (40)", "vmcnt wait (half 0)", "barrier wait"]

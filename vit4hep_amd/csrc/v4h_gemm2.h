@@ -406,6 +406,10 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       for (int t = 0; t < nt; ++t) {
         // ---- load slot
         V4H_G2_STAMP(0);
+        // (Measured and dropped: the fragment reads between the P and the Q part of the request, so that they issue while the memory path digests the
+        //  first DMA instructions - K-contiguous operands +-1 %, K-strided ones 12-25 % slower (dgrad fc1 36.4 -> 41.9 us, wgrad fc2 50.5 -> 63.1); and the
+        //  bias-gradient column sums accumulated in registers over the tile with one set of atomics per tile instead of one per duty slab - wgrad fc2
+        //  50.5 -> 56.0 us, the others +-2 %.)
         read_frags(pA, qA, c_slot, std::integral_constant<int, 0>{});
         read_frags(pB, qB, c_slot, std::integral_constant<int, 1>{});
         auto p_part = [&]() {
