@@ -210,18 +210,20 @@ def _int_operands(shape, gen, lo=-3, hi=4):
 def test_wgrad_slab_operator_exact(kernel):
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(5)
-    K, I, J = 4000, 320, 480  # K not a multiple of the split; I spans a partial 256-row tile
-    P, Q = _int_operands((K, I), gen), _int_operands((K, J), gen)
     lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
     try:
-        for splitk in (4, 8):
-            out = torch.ones((I, J), device=U.DEV)
-            cs = torch.zeros(I, device=U.DEV)
-            slab = torch.empty((splitk, I, J), device=U.DEV)
-            _lib.check(lib.v4h_op_gemm_wgrad_slab(_lib.MODES["bf16"], _lib.ptr(P), I, _lib.ptr(Q), J, _lib.ptr(slab), _lib.ptr(out), I, J, K, splitk, _lib.ptr(cs),
-                                                  _lib.stream_ptr(U.DEV)), "wgrad_slab")
-            assert torch.equal(out, P.float().t() @ Q.float() + 1.0)  # accumulates into the gradient tensor
-            assert torch.equal(cs, P.float().sum(0))
+        # K not a multiple of the split, I spans a partial 256-row tile; then 96 tiles x 4 splits = 384 tile visits: on the ring kernel (at most 256
+        # persistent workgroups) half of the workgroups walk two tiles - tile seams, bias-gradient duties of both
+        for K, I, J, splits in ((4000, 320, 480, (4, 8)), (1600, 1920, 1920, (4,))):
+            P, Q = _int_operands((K, I), gen), _int_operands((K, J), gen)
+            for splitk in splits:
+                out = torch.ones((I, J), device=U.DEV)
+                cs = torch.zeros(I, device=U.DEV)
+                slab = torch.empty((splitk, I, J), device=U.DEV)
+                _lib.check(lib.v4h_op_gemm_wgrad_slab(_lib.MODES["bf16"], _lib.ptr(P), I, _lib.ptr(Q), J, _lib.ptr(slab), _lib.ptr(out), I, J, K, splitk, _lib.ptr(cs),
+                                                      _lib.stream_ptr(U.DEV)), "wgrad_slab")
+                assert torch.equal(out, P.float().t() @ Q.float() + 1.0), (K, I, J, splitk)  # accumulates into the gradient tensor
+                assert torch.equal(cs, P.float().sum(0)), (K, I, J, splitk)
     finally:
         lib.v4h_debug_set_gemm_cfg(0, -1)
 
@@ -235,7 +237,8 @@ def test_ring_kernel_forward_and_dgrad_exact(qks, kernel):
     gen = torch.Generator(device=U.DEV).manual_seed(6)
     lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
     try:
-        for I, J, K in ((2500, 480, 480), (2304, 320, 1440), (4100, 160, 200), (40000, 480, 224)):
+        # (last three: the shortest K the ring allows - three stages; one column tile with a ragged last row tile; 9 column tiles, K tail of 8)
+        for I, J, K in ((2500, 480, 480), (2304, 320, 1440), (4100, 160, 200), (40000, 480, 224), (2048, 320, 192), (2049, 160, 1000), (3000, 1440, 488)):
             P = _int_operands((I, K), gen)
             Q = _int_operands((K, J) if qks else (J, K), gen)
             bias = torch.randint(-4, 5, (J,), generator=gen, device=U.DEV).float()

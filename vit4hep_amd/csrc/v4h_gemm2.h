@@ -8,14 +8,24 @@
 //     it is read, counted `s_waitcnt vmcnt(n)` only (the exact number of younger vector-memory instructions this wave has issued
 //     is tracked in scalar registers), one raw `s_barrier` per K-step, and the request stream runs straight on into the
 //     workgroup's NEXT output tile, so neither the pipeline fill nor the epilogue stalls the matrix pipe.
-//   * fragments are read one K = 32 slab ahead of the MFMAs that use them (two fragment sets), so the LDS latency sits behind
-//     20 MFMAs instead of in front of them; the barrier is placed in the middle of a K-step, between the two slabs.
+//   * (lock-step schedule) fragments are read one K = 32 slab ahead of the MFMAs that use them (two fragment sets), so the LDS latency sits
+//     behind 20 MFMAs instead of in front of them; the barrier is placed in the middle of a K-step, between the two slabs.
 //   * the epilogue never touches LDS: `v_permlane16_swap` turns two 16 x 16 accumulator tiles into 8 consecutive columns per lane,
 //     i.e. 16-byte bf16 / 32-byte f32 row segments, written with buffer stores whose bounds check replaces every branch
 //     (a skipped store would falsify the vmcnt bookkeeping).  The bias is DMA-ed into LDS with the tile's first stage and the
 //     accumulators START from it.
 //   * bias gradients of the wgrad form: an extra MFMA against an all-ones fragment, the duty rotating over the waves that hold
 //     the same P fragments (one slab in ntj * WJ each).
+//
+// Two schedules share all of the above (Gemm2Cfg<..., PP>):
+//   * lock-step (the first one; now the host of the ablation builds): all eight waves run the same phase - fragments one K = 32 slab ahead
+//     of the MFMAs, the request in the middle of the second MFMA group, one barrier per K-step.  Every overhead that was removed from it by
+//     ablation came back 1 : 1 as time: both waves of a SIMD push their DMA instructions (about 100 clocks each for the issuing wave) at the
+//     same moment, and a wave issues in order, so the MFMAs behind them wait.
+//   * ping-pong (the default wherever the kernel is used): per SIMD one wave runs a LOAD slot (all 18 fragment reads of a stage, its share of
+//     the DMA of the stage two ahead, at a seam the previous tile's epilogue) while its partner runs a MATRIX slot (the 40 MFMAs of the stage
+//     it loaded one slot earlier) - half 0 (waves 0..3) load, matrix, barrier; half 1 matrix of the previous stage, load, barrier: one barrier
+//     per stage, the halves in anti-phase by construction.  DESIGN.md section 5 "What round 2 found" 8, profiles/r02_gemm2_pingpong_timeline.txt.
 #pragma once
 #include "v4h_gemm.h"
 
@@ -361,14 +371,14 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
   };
 
   // ------------------------------------------------------------------ ping-pong schedule (C::PP)
-  // The waves w and w + 4 of a workgroup share a SIMD.  Time is cut into slots separated by one s_barrier each; in every slot one of the two
-  // runs a LOAD slot (both K = 32 fragment sets of a stage from LDS into registers, its share of the DMA of the stage two ahead, at a tile seam
-  // the previous tile's epilogue) while its partner runs a MATRIX slot (the 40 MFMAs of the stage it loaded one slot earlier): the matrix pipe
-  // of the SIMD always has a wave with nothing but MFMAs to issue, and the slow instructions (a global->LDS DMA instruction occupies the issuing
-  // wave for 60-180 cycles) sit in the partner's shadow.  Half 0 (waves 0..3) loads stage s in slot 2s and multiplies in slot 2s + 1, half 1
-  // one slot later.  Ring discipline: stage s + 2 goes into the slot of stage s - 1, which half 1 finished reading in slot 2s - 1; a wave makes
-  // sure its share of stage s + 1 has landed (counted vmcnt: everything it issued after that share may stay in flight) before the barrier that
-  // ends slot 2s + 1 - for half 0 that is the end of its matrix slot, for half 1 the end of its load slot.
+  // The waves w and w + 4 of a workgroup share a SIMD.  Per stage every wave runs a LOAD slot (both K = 32 fragment sets of the stage from LDS into
+  // registers, its share of the DMA of the stage two ahead, at a tile seam the previous tile's epilogue) and a MATRIX slot (the 40 MFMAs on those
+  // fragments), and the two waves of a SIMD run them in anti-phase: half 0 (waves 0..3) load(s), matrix(s), barrier; half 1 matrix(s - 1), load(s),
+  // barrier.  The matrix pipe of the SIMD (almost) always has a wave with nothing but MFMAs to issue, and the slow instructions (a global->LDS DMA
+  // instruction occupies the issuing wave for about 100 clocks) sit in the partner's shadow.  Ring discipline: stage s + 2 goes into the ring slot of
+  // stage s - 1, which every wave finished reading before the barrier that ended stage s - 1; before the barrier that ends stage s a wave makes sure its
+  // share of stage s + 1 has landed (counted vmcnt: everything it issued after that share may stay in flight).  One barrier per stage is all the data
+  // needs; the first form of the schedule had one after every slot (V4H_PP_FLAGS bit 1 brings it back): it only pinned the phases, and cost 3-7 %.
   if constexpr (C::PP) {
     static_assert(!(C::DBG & ~3), "the other ablation builds belong to the lock-step schedule");
     const int half = wave >> 2;
