@@ -17,6 +17,10 @@ def short(n):
         t, _, pks, qks, bi, bj, bk, epi, cs = m.groups()
         lay = {("0", "0"): "fwd", ("0", "1"): "dgrad", ("1", "1"): "wgrad"}[(pks, qks)]
         return f"gemm {lay} epi{epi}"
+    m = re.match(r"v4h_gemm2_kernel<Gemm2Cfg<(true|false), (true|false), (\d+), (true|false), (\d+)(?:, (true|false))? ?> ?>", n)
+    if m:
+        lay = {("false", "false"): "fwd", ("false", "true"): "dgrad", ("true", "true"): "wgrad"}[(m.group(1), m.group(2))]
+        return f"gemm2 {lay} epi{m.group(3)} {'pp' if m.group(6) == 'true' else 'ls'}"
     m = re.match(r"_ZN(?:3v4h)?12_GLOBAL__N_1(\d+)([a-z_0-9]+)", n)
     if m: return m.group(2)[:int(m.group(1))]
     return n[:50]

@@ -53,6 +53,7 @@ struct v4h_plan {
   // Linear both consume dY and are independent, so they run concurrently and fill each other's idle CUs / tile tails.
   // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
   mutable hipStream_t side = nullptr;
+  mutable hipStream_t side2 = nullptr;  // third queue for the head and the tail of a pass: chains of small, latency-bound kernels that are independent of each other
   mutable hipEvent_t ev[8] = {};
   mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable int evi = 0;
@@ -87,6 +88,13 @@ static int side_init(const v4h_plan& p) {
   else
     se = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
   if (se != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
+  // A third queue (the remaining priority class) for the t_embedder chains at the two ends of a pass.  V4H_THIRD_QUEUE=0: they stay on the side stream.
+  const char* tq = getenv("V4H_THIRD_QUEUE");
+  if (!(tq && tq[0] == '0') && greatest != least) {
+    const int other = (pe && pe[0] == 'l') ? greatest : least;
+    if (hipStreamCreateWithPriority(&p.side2, hipStreamNonBlocking, other) != hipSuccess) p.side2 = nullptr;
+  }
+  if (!p.side2) p.side2 = p.side;
   // The events only order the two streams of this device against each other; nobody inspects them from the host, so recording one
   // needs no system-scope release (an L2 write-back + ~6 us bubble in front of the next kernel of the recording stream, 30 times per
   // step: 180.1 -> 182.8 steps/s).  The kernels' own agent-scope release at their end is what the other stream's kernels need.
@@ -104,6 +112,13 @@ static int side_init(const v4h_plan& p) {
 static int side_wait_main(const v4h_plan& p, hipStream_t main) {
   hipEvent_t e = p.ev[p.evi++ & 7];
   if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(p.side, e, 0) != hipSuccess) { v4h_set_error("fork failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
+// `waiter` waits for everything enqueued on `signaler` so far
+static int stream_wait(const v4h_plan& p, hipStream_t waiter, hipStream_t signaler) {
+  if (waiter == signaler) return V4H_OK;
+  hipEvent_t e = p.ev[p.evi++ & 7];
+  if (hipEventRecord(e, signaler) != hipSuccess || hipStreamWaitEvent(waiter, e, 0) != hipSuccess) { v4h_set_error("stream fork / join failed"); return V4H_ERR_HIP; }
   return V4H_OK;
 }
 // the main stream waits for everything enqueued on the side stream so far
@@ -493,8 +508,13 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // independent chains of small launch-latency-bound kernels until the first block: they run side by side.
   RUN(side_init(*p));
   const bool fork = g_overlap_wgrad;
-  hipStream_t cs = c.s;  // stream of the conditioning path
-  if (fork) { RUN(side_wait_main(*p, c.s)); cs = p->side; }
+  hipStream_t cs = c.s, ts = c.s;  // streams of the conditioning path: c_embedder + sum + adaLN table / first half of the t_embedder
+  if (fork) {
+    RUN(side_wait_main(*p, c.s));
+    cs = p->side;
+    ts = same_c ? cs : p->side2;  // (no c_embedder work to run beside: the extra hop between queues would only cost - 1271 vs 1280 showers/s)
+    RUN(stream_wait(*p, ts, c.s));
+  }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
   char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
   if (pmap) RUN(patchify_map(m, false, x, pmap, patches, B, p->V, T, p->P, p->Ppad, c.s));
@@ -529,10 +549,11 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       a.e.out = w.cemb; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B);  // (silu_c: overwritten below)
       RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
     }
-    RUN(timestep_embed(m, t, w.temb, B, p->F, cs));
+    RUN(timestep_embed(m, t, w.temb, B, p->F, ts));
     a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
     a.e.out = w.ht; a.e.ldo = D; a.e.out2 = w.ht_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_T0B);
-    RUN(gemm_fwd(m, EPI_SILU, a, cs));
+    RUN(gemm_fwd(m, EPI_SILU, a, ts));
+    RUN(stream_wait(*p, cs, ts));  // h_t beside c_emb
     a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
     a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B); a.e.resid = w.cemb; a.e.ld_resid = D;
     RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
@@ -647,6 +668,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   layout(*p, B, true, (char*)ws, c.w);
   const WS& w = c.w;
   const Mode m = p->mode;
+  bool t_chain_forked = false;  // the t_embedder chain of the last stage went to the third queue: joined at the end
   const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
   RUN(side_init(*p));
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
@@ -807,13 +829,15 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       }
       if (ov && !batch_ada) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
-      if (ov) RUN(side_wait_main(*p, c.s));  // d cond ready
-      // t_embedder
-      RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B], sx));
+      // t_embedder: a chain of its own (third queue) - it only needs d cond, not the x_embedder / adaLN weight gradients queued on the side stream
+      hipStream_t st2 = ov ? p->side2 : c.s;
+      if (ov) RUN(stream_wait(*p, st2, c.s));  // d cond ready
+      RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B], st2));
       GemmArgs a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
       a.e.out = w.dh_small2; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
-      RUN(gemm_dgrad(m, EPI_DSILU, a, sx));
-      RUN(wgrad(c, w.dh_small2, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B], sx));
+      RUN(gemm_dgrad(m, EPI_DSILU, a, st2));
+      RUN(wgrad(c, w.dh_small2, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B], st2));
+      t_chain_forked = ov && st2 != p->side;
       // c_embedder
       RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
       a = gargs(w.dcond, D, c.W(P_C2W), D, B, D, D);
@@ -836,6 +860,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
   // kernel is left reading a temporary the next call may overwrite.
   if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));
+  if (t_chain_forked) RUN(stream_wait(*p, c.s, p->side2));
   if (stage_last == depth + 1) RUN(stage_done(depth + 1, c.s));
   return V4H_OK;
 }
