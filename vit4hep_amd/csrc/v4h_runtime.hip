@@ -728,7 +728,8 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       // The main stream may not write a set before the weight gradients of block i+2, its previous readers, are done: ONE wait per block
       // (for the mark that block left behind its last weight gradient - two blocks old, long reached) instead of one per temporary.
       // [Tried: fewer forks - they cost a record packet each - by handing the side stream all four weight gradients at the block's end
-      // (186.5 vs 189.2 steps/s) or two at a time (186.8 vs 193.6): how finely the two streams interleave matters more than the packets.]
+      // (186.5 vs 189.2 steps/s) or two at a time (186.8 vs 193.6; again with the ring kernels of round 2: 219.7 vs 221.6): how finely the two
+      // streams interleave matters more than the packets.]
       auto wg = [&](int k) -> int {
         switch (k) {
           case 0: return wgrad(c, dy_i, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_);
