@@ -250,6 +250,39 @@ def test_ring_kernel_forward_and_dgrad_exact(qks, kernel):
         lib.v4h_debug_set_gemm_cfg(0, -1)
 
 
+def test_ring_kernel_random_shapes_exact():
+    """Seeded random problem sizes through both schedules of the ring kernel, all three operand layouts (row counts with ragged last tiles, every column
+    tile count from 1 to 12, K from the three-stage minimum up, K tails, one to three tiles per persistent workgroup)."""
+    lib = _lib.load()
+    gen = torch.Generator(device=U.DEV).manual_seed(17)
+    rng = np.random.default_rng(17)
+    cases = [(int(rng.integers(2048, 60000)), 160 * int(rng.integers(1, 13)), 8 * int(rng.integers(24, 260))) for _ in range(10)]
+    try:
+        for kernel in (2, 9):
+            lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+            for I, J, K in cases:
+                if I * J > 40_000_000:
+                    I = 40_000_000 // J
+                for qks in (0, 1):
+                    P = _int_operands((I, K), gen, -2, 3)
+                    Q = _int_operands((K, J) if qks else (J, K), gen, -2, 3)
+                    bias = torch.randint(-4, 5, (J,), generator=gen, device=U.DEV).float()
+                    out = U.gemm("bf16", P, Q, I, J, K, 0, qks, bias=bias)
+                    want = P.float() @ (Q.float() if qks else Q.float().t()) + bias
+                    assert torch.equal(out.float(), want.to(torch.bfloat16).float()), (kernel, I, J, K, qks)
+            for I, J, K, splitk in ((1440, 480, 9000, 8), (1920, 960, 5000, 5), (328, 160, 2600, 3)):
+                P, Q = _int_operands((K, I), gen, -2, 3), _int_operands((K, J), gen, -2, 3)
+                out = torch.zeros((I, J), device=U.DEV)
+                cs = torch.zeros(I, device=U.DEV)
+                slab = torch.empty((splitk, I, J), device=U.DEV)
+                _lib.check(lib.v4h_op_gemm_wgrad_slab(_lib.MODES["bf16"], _lib.ptr(P), I, _lib.ptr(Q), J, _lib.ptr(slab), _lib.ptr(out), I, J, K, splitk, _lib.ptr(cs),
+                                                      _lib.stream_ptr(U.DEV)), "wgrad_slab")
+                assert torch.equal(out, P.float().t() @ Q.float()), (kernel, I, J, K, splitk)
+                assert torch.equal(cs, P.float().sum(0)), (kernel, I, J, K, splitk)
+    finally:
+        lib.v4h_debug_set_gemm_cfg(0, -1)
+
+
 def test_update_step_on_the_ping_pong_kernel_matches_the_default_dispatch():
     """Every epilogue the ring kernel has (plain store, GELU with its saved derivative, the DGELU dgrad, split-K slabs with bias sums) inside one
     loss + backward at a token count above its threshold: gradients against the two-workgroup kernel's on the same inputs.  Both accumulate each
