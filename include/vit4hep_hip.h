@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 6
+#define V4H_ABI_VERSION 7
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -186,7 +186,9 @@ int32_t v4h_sq_norm_accum(const float* d_g, int64_t n, float* d_out, void* strea
  * configs/training/default.yaml:5-10).  step >= 1 is the AdamW step count.  With d_gnorm_sq given (max_norm = +inf for "no clipping", which is
  * what the reference passes) a non-finite gradient norm leaves parameters and moments untouched and increments *d_nonfinite (optional, sticky,
  * device memory): the reference raises at that point (clip_grad_norm_(error_if_nonfinite=True), base_experiment.py:573-585), the caller of
- * this asynchronous form raises when it next looks at the flag.  d_gnorm_sq == NULL: no clipping and no guard. */
+ * this asynchronous form raises when it next looks at the flag.  While *d_nonfinite is non-zero EVERY later call skips (and counts) its update
+ * as well, so the state the caller finds is exactly the one of the last finite step and no update was applied with a shifted step index; the caller
+ * zeroes the counter to resume.  d_gnorm_sq == NULL: no clipping and no norm guard (a non-zero counter still holds updates back). */
 int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int32_t step, void* stream, int32_t* d_nonfinite);
 /* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
@@ -218,8 +220,16 @@ int32_t v4h_op_unpatchify(const v4h_plan* plan, const float* d_tokens, float* d_
 /* learnable_pos_embedding   nn/vit.py:156-162 -> (T, D) f32 */
 int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe, void* stream, const float* d_pos);
 
-/* tuning hook (tools/gemm_bench.py only): selects the tile configuration of the plain-store and wgrad contractions */
-void v4h_debug_set_gemm_cfg(int32_t cfg, int32_t cfg_wgrad);
+/* Which hand-written kernel serves the token-sized bf16 contractions (every Linear of a DiT block, nn/vit.py:317-322,416,420, and their dgrad /
+   wgrad).  All choices compute the same contraction exactly (f32 accumulation in the same k order; they differ in where the bias enters the sum, i.e. in
+   bf16 rounding): 0 = automatic (the measured winner per contraction class, the default), 1 = the 128 x 160 two-workgroup kernel everywhere,
+   2 = the 256 x 160 ring kernel wherever the shape is eligible.  Process-global, read at launch time: set it while no call of another thread is being
+   enqueued.  Used by the parity tests (bit-identical results across batch sizes need ONE kernel) and by A/B measurements.  Any other value is
+   refused (V4H_ERR_ARG) and leaves the selection unchanged; ablation builds of the kernels exist only in libraries compiled with -DV4H_ABLATIONS
+   and are not reachable through this header.  The environment variable V4H_GEMM2 (-1 / 0 / 8 = the same three choices) sets the initial value;
+   other values are ignored with a message on stderr. */
+int32_t v4h_select_contraction_kernel(int32_t which);
+int32_t v4h_selected_contraction_kernel(void);
 
 #ifdef __cplusplus
 }

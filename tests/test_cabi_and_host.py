@@ -4,6 +4,7 @@ host mirror classes keep the reference's constructor, state-dict keys and initia
 import ctypes
 import math
 import os
+import sys
 import re
 
 import numpy as np
@@ -29,7 +30,30 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 7
+
+
+def test_product_library_contains_no_ablation_kernels_and_refuses_to_select_one():
+    """The ablation builds of the contraction kernels (some wrong by construction: no DMA after the first ring fill, one store per tile ...) and the
+    tuning hook that selected them exist only under -DV4H_ABLATIONS.  A default build exports none of them, ignores an environment that asks for one and
+    refuses any selection other than the three exact kernels."""
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "v4h_debug_" not in syms
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"dbg1", b"dbg2", b"dbg3", b"V4H_GEMM_CFG", b"V4H_GEMM_WCFG", b"V4H_THIRD_QUEUE", b"V4H_PP_FLAGS", b"V4H_GEMM_STRIPS"):
+        assert needle not in blob, needle
+    # mangled names of the ring kernel's instantiations: Gemm2Cfg<PKS, QKS, EPI, COLSUM, DBG, PP> - DBG must be 0 and PP true in every one
+    for m in re.finditer(rb"8Gemm2CfgILb[01]ELb[01]ELi\d+ELb[01]ELi(\d+)ELb([01])EE", blob):
+        assert m.group(1) == b"0" and m.group(2) == b"1", m.group(0)
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); print(lib.v4h_selected_contraction_kernel(), lib.v4h_select_contraction_kernel(3), "
+            "lib.v4h_select_contraction_kernel(-1), lib.v4h_selected_contraction_kernel(), lib.v4h_select_contraction_kernel(2), lib.v4h_selected_contraction_kernel())")
+    for env_val, first in (("3", 0), ("10", 0), ("0", 1), ("8", 2), ("-1", 0)):
+        env = dict(os.environ, V4H_GEMM2=env_val)
+        r = subprocess.run([sys.executable, "-c", code, _lib.LIB_PATH], capture_output=True, text=True, env=env, check=True)
+        assert r.stdout.split() == [str(first), "1", "1", str(first), "0", "2"], (env_val, r.stdout, r.stderr)
+        assert ("ignored" in r.stderr) == (env_val in ("3", "10")), r.stderr
 
 
 def test_plan_inventory_matches_reference_state_dict():

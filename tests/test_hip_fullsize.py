@@ -45,7 +45,7 @@ def test_forward_is_batch_independent_and_matches_oracle_rows(mode):
         # end: the same sums in another rounding order, so there the rows agree to bf16 rounding.
         for pinned in (True, False):
             if pinned:
-                lib.v4h_debug_set_gemm_cfg(0, 1000)
+                _lib.check(lib.v4h_select_contraction_kernel(_lib.KERNEL_TWO_WG), "select")
             try:
                 full = model.forward(xt, t.view(-1, 1), c)
                 for lo, hi in ((0, 8), (56, 72), (120, 128)):
@@ -55,7 +55,7 @@ def test_forward_is_batch_independent_and_matches_oracle_rows(mode):
                     else:
                         assert U.rel_err(part, full[lo:hi]) < 1e-2, (mode, lo)
             finally:
-                lib.v4h_debug_set_gemm_cfg(0, -1)
+                lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
     rows = slice(60, 62)
     ref = O.cfm_forward(O.golden_fill(CFG), xt[rows].cpu(), t[rows].view(-1, 1).cpu(), c[rows].cpu(), CFG)
     assert U.rel_err(full[rows], ref) < (1e-4 if mode == "f32" else 3e-2)

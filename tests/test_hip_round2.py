@@ -94,7 +94,7 @@ def test_ds3_b64_forward_is_batch_independent_and_matches_oracle_rows(mode):
         # kernels (the ring kernel's accumulators start from the bias): tests/test_hip_fullsize.py
         for pinned in (True, False):
             if pinned:
-                lib.v4h_debug_set_gemm_cfg(0, 1000)
+                _lib.check(lib.v4h_select_contraction_kernel(_lib.KERNEL_TWO_WG), "select")
             try:
                 full = model.forward(xt, t.view(-1, 1), c)
                 for lo, hi in ((0, 4), (29, 35), (60, 64)):
@@ -104,7 +104,7 @@ def test_ds3_b64_forward_is_batch_independent_and_matches_oracle_rows(mode):
                     else:
                         assert U.rel_err(part, full[lo:hi]) < 1e-2, (mode, lo)
             finally:
-                lib.v4h_debug_set_gemm_cfg(0, -1)
+                lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
     rows = slice(31, 32)
     ref = O.cfm_forward(O.golden_fill(CFG3), xt[rows].cpu(), t[rows].view(-1, 1).cpu(), c[rows].cpu(), CFG3)
     assert U.rel_err(full[rows], ref) < (1e-4 if mode == "f32" else 3e-2)
@@ -149,6 +149,14 @@ def test_ddp_wrapped_net_matches_single_process_gradients():
     for mode in ("f32", "bf16"):
         plain = U.build_models(cfg, mode, fill)
         l0, g0 = _grads(plain, x, c, t, x0)
+        # The per-sample reductions of the backward (adaLN modulation gradients) are f32 atomic sums whose order varies from run to run; in bf16 mode a
+        # last-bit change there can flip a bf16 rounding downstream.  Measure that spread on the SAME tensors without DDP (four more plain runs) ...
+        spread = {k: 0.0 for k in g0}
+        for _ in range(4):
+            again = U.build_models(cfg, mode, fill)
+            _, ga = _grads(again, x, c, t, x0)
+            for k in g0:
+                spread[k] = max(spread[k], U.rel_err(ga[k], g0[k]))
         os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0", "WORLD_SIZE": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         dist.init_process_group("nccl", init_method="env://", device_id=torch.device(U.DEV))
         try:
@@ -164,8 +172,8 @@ def test_ddp_wrapped_net_matches_single_process_gradients():
         finally:
             dist.destroy_process_group()
         assert abs(l1 - l0).item() / l0.item() < 1e-6
-        for k in g0:  # (per-sample reductions use float atomics: order varies run to run)
-            assert U.rel_err(g1[k], g0[k]) < (1e-5 if mode == "f32" else 5e-3), (mode, k)  # bf16: a last-bit change of an f32 atomic sum can flip a bf16 rounding downstream
+        for k in g0:  # ... and hold DDP to twice the spread the plain path shows on that tensor (floors: f32 1e-5, bf16 2e-3 = the deterministic part)
+            assert U.rel_err(g1[k], g0[k]) <= max(1e-5 if mode == "f32" else 2e-3, 2.0 * spread[k]), (mode, k, spread[k])
 
 
 # ---------------------------------------------------------------------------------------------------------------- non-finite gradients
@@ -191,6 +199,10 @@ def _nonfinite_body(clip):
     assert not np.isfinite(gn.item())
     assert torch.equal(tr.flat_p, before[0]) and torch.equal(tr.flat_m, before[1]) and torch.equal(tr.flat_v, before[2])  # nothing applied
     assert tr.step_count == 2
+    # the counter is sticky: a later step with FINITE gradients is held back too until the host has looked (no update with a shifted step index)
+    _, gn_ok = tr.step(x, c, t, x0)
+    assert np.isfinite(gn_ok.item()) and tr.step_count == 3
+    assert torch.equal(tr.flat_p, before[0]) and torch.equal(tr.flat_m, before[1]) and torch.equal(tr.flat_v, before[2])
     with pytest.raises(RuntimeError, match="non-finite"):
         tr.raise_if_nonfinite()
     assert tr.step_count == 1  # rewound to the last applied update
@@ -206,11 +218,11 @@ def _int_operands(shape, gen, lo=-3, hi=4):
     return torch.randint(lo, hi, shape, generator=gen, device=U.DEV).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 9])  # 1: 128 x 160 two-workgroup kernel (v4h_gemm.h), 2: 256 x 160 ring kernel (v4h_gemm2.h), 9: its ping-pong schedule
+@pytest.mark.parametrize("kernel", [_lib.KERNEL_TWO_WG, _lib.KERNEL_RING])  # 128 x 160 two-workgroup kernel (v4h_gemm.h), 256 x 160 ring kernel (v4h_gemm2.h)
 def test_wgrad_slab_operator_exact(kernel):
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(5)
-    lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+    _lib.check(lib.v4h_select_contraction_kernel(kernel), "select")
     try:
         # K not a multiple of the split, I spans a partial 256-row tile; then 96 tiles x 4 splits = 384 tile visits: on the ring kernel (at most 256
         # persistent workgroups) half of the workgroups walk two tiles - tile seams, bias-gradient duties of both
@@ -225,17 +237,16 @@ def test_wgrad_slab_operator_exact(kernel):
                 assert torch.equal(out, P.float().t() @ Q.float() + 1.0), (K, I, J, splitk)  # accumulates into the gradient tensor
                 assert torch.equal(cs, P.float().sum(0)), (K, I, J, splitk)
     finally:
-        lib.v4h_debug_set_gemm_cfg(0, -1)
+        lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
 
 
-@pytest.mark.parametrize("kernel", [2, 9])  # lock-step and ping-pong schedule
 @pytest.mark.parametrize("qks", [0, 1])
-def test_ring_kernel_forward_and_dgrad_exact(qks, kernel):
+def test_ring_kernel_forward_and_dgrad_exact(qks):
     """v4h_gemm2.h through v4h_op_gemm: K tails (K % 64 != 0), a partial last row tile, several column tiles, bias; enough row tiles that persistent
     workgroups walk several tiles each (tile seams, bias slots of both parities)."""
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(6)
-    lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+    _lib.check(lib.v4h_select_contraction_kernel(_lib.KERNEL_RING), "select")
     try:
         # (last three: the shortest K the ring allows - three stages; one column tile with a ragged last row tile; 9 column tiles, K tail of 8)
         for I, J, K in ((2500, 480, 480), (2304, 320, 1440), (4100, 160, 200), (40000, 480, 224), (2048, 320, 192), (2049, 160, 1000), (3000, 1440, 488)):
@@ -247,19 +258,19 @@ def test_ring_kernel_forward_and_dgrad_exact(qks, kernel):
             # integer operands: the f32 accumulation is exact, the only rounding is the final one to bf16
             assert torch.equal(out.float(), want.to(torch.bfloat16).float()), (I, J, K)
     finally:
-        lib.v4h_debug_set_gemm_cfg(0, -1)
+        lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
 
 
 def test_ring_kernel_random_shapes_exact():
-    """Seeded random problem sizes through both schedules of the ring kernel, all three operand layouts (row counts with ragged last tiles, every column
+    """Seeded random problem sizes through the ring kernel, all three operand layouts (row counts with ragged last tiles, every column
     tile count from 1 to 12, K from the three-stage minimum up, K tails, one to three tiles per persistent workgroup)."""
     lib = _lib.load()
     gen = torch.Generator(device=U.DEV).manual_seed(17)
     rng = np.random.default_rng(17)
     cases = [(int(rng.integers(2048, 60000)), 160 * int(rng.integers(1, 13)), 8 * int(rng.integers(24, 260))) for _ in range(10)]
     try:
-        for kernel in (2, 9):
-            lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+        for kernel in (_lib.KERNEL_RING,):
+            _lib.check(lib.v4h_select_contraction_kernel(kernel), "select")
             for I, J, K in cases:
                 if I * J > 40_000_000:
                     I = 40_000_000 // J
@@ -280,7 +291,7 @@ def test_ring_kernel_random_shapes_exact():
                 assert torch.equal(out, P.float().t() @ Q.float()), (kernel, I, J, K, splitk)
                 assert torch.equal(cs, P.float().sum(0)), (kernel, I, J, K, splitk)
     finally:
-        lib.v4h_debug_set_gemm_cfg(0, -1)
+        lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
 
 
 def test_update_step_on_the_ping_pong_kernel_matches_the_default_dispatch():
@@ -294,8 +305,8 @@ def test_update_step_on_the_ping_pong_kernel_matches_the_default_dispatch():
     t, x0 = O.synthetic_noise(cfg, 24, g)
     x, c, t, x0 = x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV)
     res = {}
-    for kernel in (1, 9):
-        lib.v4h_debug_set_gemm_cfg(0, 1000 * kernel)
+    for kernel in (_lib.KERNEL_TWO_WG, _lib.KERNEL_RING):
+        _lib.check(lib.v4h_select_contraction_kernel(kernel), "select")
         try:
             model = U.build_models(cfg, "bf16", fill)
             loss = model._loss_from_noise(x, c, t, x0)
@@ -303,10 +314,10 @@ def test_update_step_on_the_ping_pong_kernel_matches_the_default_dispatch():
             torch.cuda.synchronize()
             res[kernel] = (loss.item(), {k: v.clone() for k, v in U.named_grads(model).items()})
         finally:
-            lib.v4h_debug_set_gemm_cfg(0, -1)
-    assert abs(res[1][0] - res[9][0]) < 2e-3 * abs(res[1][0])
+            lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
+    assert abs(res[1][0] - res[2][0]) < 2e-3 * abs(res[1][0])
     for k, ref in res[1][1].items():
-        assert U.rel_err(res[9][1][k], ref) < 2e-2, k
+        assert U.rel_err(res[2][1][k], ref) < 2e-2, k
 
 
 # ---------------------------------------------------------------------------------------------------------------- hipGraph capture

@@ -10,6 +10,9 @@ from vit4hep_amd import _lib
 which = sys.argv[1] if len(sys.argv) > 1 else "fc1"
 ver = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 lib = _lib.load()
+from tools._abl import require_ablation_lib
+require_ablation_lib(lib)
+
 raw = C.CDLL(_lib.LIB_PATH)
 dev = "cuda:0"
 BT = 17280

@@ -13,6 +13,9 @@ from vit4hep_amd import _lib
 BT = int(sys.argv[1]) if len(sys.argv) > 1 else 17280
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 lib = _lib.load()
+from _abl import require_ablation_lib
+require_ablation_lib(lib)
+
 dev = "cuda:0"
 D, M = 480, 1920
 dt = torch.bfloat16

@@ -9,6 +9,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 BT = int(sys.argv[2]) if len(sys.argv) > 2 else 17280
 dt = torch.bfloat16 if mode == "bf16" else torch.float32
 lib = _lib.load()
+from _abl import require_ablation_lib
+require_ablation_lib(lib)
+
 dev = "cuda:0"
 D, M = 480, 1920
 

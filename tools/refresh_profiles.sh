@@ -1,6 +1,6 @@
 #!/bin/bash
 # Re-measure everything profiles/ quotes for the update step, on the GPU box:  bash tools/refresh_profiles.sh <tag>
-# Writes gpurun_out/refresh_<tag>/...; copy what should be judged into profiles/ (tools/collect_profiles.sh <tag> does).
+# Writes gpurun_out/refresh_<tag>/...; copy what should be judged into profiles/ (python tools/collect_profiles.py <tag> does).
 set -e -o pipefail
 tag=${1:-r02}
 out=gpurun_out/refresh_$tag
@@ -27,10 +27,10 @@ for w in ds3 ds2_d2 lemurs ds1_photons ds1_pions calogan calohad; do
 done
 python3 bench.py --mode f32 --steps 10 --warmup 3 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_f32.json
 V4H_FORCE_COLLECTIVES=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_forced_collectives.json 2> $out/forced_collectives.err || echo "forced-collectives run failed"
-ABL=1 python3 tools/gemm2_bench.py > $out/gemm2_ablation.txt 2>&1 || true
+[ -f vit4hep_amd/libvit4hep_hip_abl.so ] && VIT4HEP_AMD_LIB=$PWD/vit4hep_amd/libvit4hep_hip_abl.so ABL=1 python3 tools/gemm2_bench.py > $out/gemm2_ablation.txt 2>&1 || true
 # in-context A/B of the alternatives that are kept behind switches (interleaved, same box)
 for r in 1 2; do
-  for v in "V4H_GEMM2=-1" "V4H_GEMM2=0" "V4H_GEMM2_PP=0" "V4H_GEMM2_PP=63" "V4H_GEMM2_PP=37" "V4H_PP_FLAGS=2" "V4H_FWD_LOCKSTEP=1" "V4H_WGRAD_WGS=256" "V4H_GEMM_STRIPS=0" "V4H_LN_RESID=0"; do
+  for v in "V4H_GEMM2=-1" "V4H_GEMM2=0" "V4H_GEMM2_PP=0" "V4H_GEMM2_PP=63" "V4H_GEMM2_PP=53" "V4H_WGRAD_WGS=256" "V4H_LN_RESID=0"; do
     echo -n "$v  " >> $out/ab_in_context.txt
     env $v python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-op-rates 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], 'steps/s', r['ms_per_step'], 'ms', r['sampling']['rk4']['showers_per_s'], 'showers/s (RK4)')" >> $out/ab_in_context.txt
   done

@@ -6,6 +6,9 @@ import torch
 from vit4hep_amd import _lib
 
 lib = _lib.load()
+from _abl import require_ablation_lib
+require_ablation_lib(lib)
+
 dev = "cuda:0"
 D, M, BT = 480, 1920, 17280
 MODE = _lib.MODES["bf16"]

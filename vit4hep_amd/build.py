@@ -16,8 +16,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "libvit4hep_hip.so")
+# V4H_BUILD_TAG=<tag>: a second build beside the product library (objects in _build_<tag>/, library libvit4hep_hip_<tag>.so; load it with
+# VIT4HEP_AMD_LIB=...).  The ablation / tuning build the tools under tools/ need:  V4H_BUILD_TAG=abl V4H_EXTRA_FLAGS=-DV4H_ABLATIONS python -m vit4hep_amd.build
+TAG = os.environ.get("V4H_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "_build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libvit4hep_hip" + ("_" + TAG if TAG else "") + ".so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"] + os.environ.get("V4H_EXTRA_FLAGS", "").split()

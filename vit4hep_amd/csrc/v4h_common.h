@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -213,3 +215,26 @@ void v4h_set_error(const char* fmt, ...);
       return V4H_ERR_HIP;                                                 \
     }                                                                     \
   } while (0)
+
+// A per-function attribute (hipFuncSetAttribute: maximum dynamic LDS) belongs to the function object of the CURRENT device, so "done once" is
+// remembered per device ordinal, not per process: one process may drive several GPUs (_lib.on_device).  Setting it twice is harmless, so two
+// threads that race to the first launch both set it and both record it.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done[4] = {};
+  template <class F> int ensure(F&& set, const char* name, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+      v4h_set_error("%s: no current device (hipGetDevice)", name);
+      return V4H_ERR_HIP;
+    }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done[dev >> 6].load(std::memory_order_acquire) & bit) return V4H_OK;
+    const hipError_t e = set();
+    if (e != hipSuccess) {
+      v4h_set_error("%s: cannot %s on device %d: %s", name, what, dev, hipGetErrorString(e));
+      return V4H_ERR_HIP;
+    }
+    done[dev >> 6].fetch_or(bit, std::memory_order_release);
+    return V4H_OK;
+  }
+};

@@ -685,16 +685,19 @@ __global__ void sq_norm_kernel(const float* __restrict__ g, long n, float* __res
 // coef = min(1, clip / (norm + 1e-6)); p *= 1 - lr wd; m,v update; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                              const float* __restrict__ gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
-                             int* __restrict__ nonfinite) {
+                             int* nonfinite) {
+  // error_if_nonfinite (base_experiment.py:581): on a non-finite gradient norm parameters and moments stay untouched and a counter tells the host.
+  // The counter is STICKY: while it is non-zero every later update is skipped (and counted) too, so when the host looks - every step or every 50 -
+  // the state is exactly the one the reference's raise would have left behind, and no update was applied with a shifted step index meanwhile.
+  // (Every thread of a launch takes the same decision: the counter only grows in launches in which all of them skip anyway.)
   float coef = 1.0f;
-  if (gnorm_sq) {
-    const float nrm = sqrtf(*gnorm_sq);
-    if (!isfinite(nrm)) {  // error_if_nonfinite (base_experiment.py:581): parameters and moments stay untouched, a sticky flag tells the host
-      if (nonfinite && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(nonfinite, 1);
-      return;
-    }
-    coef = fminf(1.0f, clip / (nrm + 1e-6f));  // clip = +inf (no clipping, the reference's max_norm = inf): 1
+  const float nrm = gnorm_sq ? sqrtf(*gnorm_sq) : 0.0f;
+  const bool stuck = nonfinite && __hip_atomic_load(nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+  if (!isfinite(nrm) || stuck) {
+    if (nonfinite && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(nonfinite, 1);
+    return;
   }
+  if (gnorm_sq) coef = fminf(1.0f, clip / (nrm + 1e-6f));  // clip = +inf (no clipping, the reference's max_norm = inf): 1
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
     float pi = p[i] * (1.0f - lr * wd);

@@ -454,12 +454,10 @@ int energy_fused_pack(const void* const* params, char* stream, int nd, int te, i
 }
 int energy_fused_decoder(const char* stream, const float* x, const float* t, const float* gfp_w, const float* te_w, const float* te_b, const float* wx, const float* bx,
                          const float* pos, const float* cv, const float* head_w, const float* head_b, float* out, int B, int L, int nd, int te, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)energy_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
-    if (e != hipSuccess) { v4h_set_error("energy_decoder: cannot reserve %zu bytes of LDS: %s", FUSED_LDS, hipGetErrorString(e)); return V4H_ERR_HIP; }
-    attr_set = true;
-  }
+  static DeviceOnce lds_attr;
+  if (int rc = lds_attr.ensure([&]() -> hipError_t {
+        return hipFuncSetAttribute((const void*)energy_decoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS);
+      }, "energy_decoder", "reserve the decoder's LDS")) return rc;
   FusedArgs a{stream, x, t, gfp_w, te_w, te_b, wx, bx, pos, cv, head_w, head_b, out, B, L, nd, te};
   hipLaunchKernelGGL(energy_decoder_kernel, dim3(B), dim3(256), FUSED_LDS, s, a);
   V4H_CHECK_LAUNCH("energy_decoder");

@@ -71,7 +71,6 @@ struct GemmArgs {
   int I, J, K;
   int klen;          // K range per split (multiple of BK)
   int stagger_sleeps;  // tuning: s_sleep(127) count (8128 cycles each) for the second half of a persistent grid
-  int sched_flags;   // ring kernel, ping-pong schedule (set by its launcher from V4H_PP_FLAGS): bit 0 = the two halves write a finished tile in the same slot
   int nti, ntj, nz;  // tiles along i, along j, K splits (filled by the launcher; 1-D grid, XCD-aware decode in the kernel)
   float* colsum;     // optional: colsum[i] += sum_k P[i][k]   (f32 atomics; only j-tile 0 contributes)
   EpiArgs e;
@@ -938,15 +937,11 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
     if (nblocks > resident) nblocks = resident;
   }
   dim3 grid((unsigned)nblocks);
-  static bool attr_set = false;
-  if (!attr_set && C::LDS_BYTES > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)C::LDS_BYTES);
-    if (e != hipSuccess) {
-      v4h_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, (size_t)C::LDS_BYTES, hipGetErrorString(e));
-      return V4H_ERR_HIP;
-    }
-    attr_set = true;
+  if constexpr (C::LDS_BYTES > 48 * 1024) {
+    static DeviceOnce lds_attr;  // the attribute belongs to the function object of ONE device
+    if (int rc = lds_attr.ensure([&]() -> hipError_t {
+          return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        }, name, "reserve the LDS of the tile")) return rc;
   }
   hipLaunchKernelGGL(v4h_gemm_kernel<C>, grid, dim3(C::NT), C::LDS_BYTES, stream, a);
   V4H_CHECK_LAUNCH(name);

@@ -72,7 +72,10 @@ template <int COLS> struct FragKS {  // K-strided image [k][COLS], transposed re
   }
 };
 
-template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0, bool PP_ = false> struct Gemm2Cfg {
+template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0, bool PP_ = true> struct Gemm2Cfg {
+#ifndef V4H_ABLATIONS
+  static_assert(DBG_ == 0 && PP_, "ablation builds (DBG != 0, lock-step schedule) need -DV4H_ABLATIONS: several of them are wrong by construction");
+#endif
   using T = bf16;
   static constexpr bool PKS = PKS_, QKS = QKS_, COLSUM = COLSUM_;
   static constexpr int EPI = EPI_, DBG = DBG_;
@@ -95,25 +98,34 @@ template <bool PKS_, bool QKS_, int EPI_, bool COLSUM_, int DBG_ = 0, bool PP_ =
 // `s_waitcnt vmcnt(n)` for a wave-uniform n that is only known at run time (gfx9 has no register form of the instruction): a computed jump into a table of
 // 49 two-instruction entries - eight scalar instructions in all.  (Written as a C++ switch the compiler lowers it to a chain of some 200 scalar compares and
 // branches, about 450 clocks on the critical path of every K-step: tools/experiments/gemm2_stamps.py.)  n above 48 waits for 48: only ever conservative.
+// The jump arithmetic assumes 8 bytes per table entry and takes the distance from the s_getpc result to the table from the assembler (label
+// difference), and the .if below fails the BUILD if an assembler ever encodes an entry in another size.  s[92:93] (the jump target needs an aligned
+// pair, which an asm operand cannot be split into) is declared clobbered; the other scratch register is the compiler's choice.
 V4H_DEV void wait_vmcnt64(int n) {
 #define V4H_VM_ROW(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch 1f\n\t"
+  unsigned t32;
   asm volatile(
-      "s_min_u32 s90, %0, 48\n\t"
-      "s_lshl_b32 s90, s90, 3\n\t"
-      "s_add_u32 s90, s90, 12\n\t"
-      "s_getpc_b64 s[92:93]\n\t"
-      "s_add_u32 s92, s92, s90\n\t"
+      "s_min_u32 %0, %1, 48\n\t"
+      "s_lshl_b32 %0, %0, 3\n\t"
+      "s_getpc_b64 s[92:93]\n"
+      "3:\n\t"
+      "s_add_u32 %0, %0, 2f-3b\n\t"
+      "s_add_u32 s92, s92, %0\n\t"
       "s_addc_u32 s93, s93, 0\n\t"
-      "s_setpc_b64 s[92:93]\n\t"
+      "s_setpc_b64 s[92:93]\n"
+      "2:\n\t"
       V4H_VM_ROW(0) V4H_VM_ROW(1) V4H_VM_ROW(2) V4H_VM_ROW(3) V4H_VM_ROW(4) V4H_VM_ROW(5) V4H_VM_ROW(6) V4H_VM_ROW(7) V4H_VM_ROW(8) V4H_VM_ROW(9)
       V4H_VM_ROW(10) V4H_VM_ROW(11) V4H_VM_ROW(12) V4H_VM_ROW(13) V4H_VM_ROW(14) V4H_VM_ROW(15) V4H_VM_ROW(16) V4H_VM_ROW(17) V4H_VM_ROW(18) V4H_VM_ROW(19)
       V4H_VM_ROW(20) V4H_VM_ROW(21) V4H_VM_ROW(22) V4H_VM_ROW(23) V4H_VM_ROW(24) V4H_VM_ROW(25) V4H_VM_ROW(26) V4H_VM_ROW(27) V4H_VM_ROW(28) V4H_VM_ROW(29)
       V4H_VM_ROW(30) V4H_VM_ROW(31) V4H_VM_ROW(32) V4H_VM_ROW(33) V4H_VM_ROW(34) V4H_VM_ROW(35) V4H_VM_ROW(36) V4H_VM_ROW(37) V4H_VM_ROW(38) V4H_VM_ROW(39)
       V4H_VM_ROW(40) V4H_VM_ROW(41) V4H_VM_ROW(42) V4H_VM_ROW(43) V4H_VM_ROW(44) V4H_VM_ROW(45) V4H_VM_ROW(46) V4H_VM_ROW(47) V4H_VM_ROW(48)
-      "1:"
-      :
+      "\n1:\n\t"
+      ".if (1b - 2b) != 49 * 8\n\t"
+      ".error \"wait_vmcnt64: a table entry is not 8 bytes\"\n\t"
+      ".endif"
+      : "=&s"(t32)
       : "s"(n)
-      : "s90", "s92", "s93", "scc", "memory");
+      : "s92", "s93", "scc", "memory");
 #undef V4H_VM_ROW
 }
 
@@ -378,12 +390,11 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
   // instruction occupies the issuing wave for about 100 clocks) sit in the partner's shadow.  Ring discipline: stage s + 2 goes into the ring slot of
   // stage s - 1, which every wave finished reading before the barrier that ended stage s - 1; before the barrier that ends stage s a wave makes sure its
   // share of stage s + 1 has landed (counted vmcnt: everything it issued after that share may stay in flight).  One barrier per stage is all the data
-  // needs; the first form of the schedule had one after every slot (V4H_PP_FLAGS bit 1 brings it back): it only pinned the phases, and cost 3-7 %.
+  // needs; the first form of the schedule had one after every slot: it only pinned the phases, and cost 3-7 % (so did letting both halves write a
+  // finished tile in the same slot of that form: neutral to -0.8 % in the step - both removed in round 3).
   if constexpr (C::PP) {
     static_assert(!(C::DBG & ~3), "the other ablation builds belong to the lock-step schedule");
     const int half = wave >> 2;
-    const bool seam_overlap = (a.sched_flags & 1) != 0;
-    const bool two_barriers = (a.sched_flags & 2) != 0;  // the first form of the schedule: a barrier after every slot (below)
     auto slot_barrier = [&]() {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
@@ -403,7 +414,6 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       wait_vmcnt64(n1);
       slot_barrier();  // stage 0 is in LDS
     }
-    if (half == 1 && two_barriers) slot_barrier();  // slot 0: half 1 has nothing to multiply yet
     int p_ti = 0, p_tj = 0, p_tz = 0;
     bool have_prev = false;
     for (;;) {
@@ -428,7 +438,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
         };
         if (C::EPI != EPI_DGELU) p_part();  // (the DGELU epilogue loads: its waits would also wait for a DMA issued in front of it)
         if (t == 0) {
-          if (have_prev && (half == 0 || !seam_overlap)) {  // (half 1 wrote its part of the previous tile at the end of its last matrix slot - in this same slot)
+          if (have_prev) {
             const int n = epilogue(p_ti, p_tj, p_tz);
             yo += n;
             yn += n;
@@ -443,7 +453,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
           yo = yn;
         }
         V4H_G2_STAMP(2);
-        if (half == 1 || two_barriers) slot_barrier();
+        if (half == 1) slot_barrier();
         __builtin_amdgcn_sched_barrier(0);
         V4H_G2_STAMP(3);
         // ---- matrix slot
@@ -466,19 +476,12 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
                                            //  measurable and cost 45 registers.)
         mfmas(pB, qB, 0, C::TI);
         V4H_G2_STAMP(4);
-        if (half == 1 && t == nt - 1 && seam_overlap) {
-          // Tile seam: half 0 is now in the load slot that starts with ITS epilogue of this tile; half 1 runs its own right here, beside it, instead
-          // of in its next load slot - the two epilogues (about 2500 clocks each) overlap instead of following each other.
-          const int n = epilogue(ti, tj, tz);
-          yo += n;
-          yn += n;
-        }
         if (half == 0) {
           wait_vmcnt64(sgpr(yo));
           yo = yn;
         }
         V4H_G2_STAMP(5);
-        if (half == 0 || two_barriers) slot_barrier();
+        if (half == 0) slot_barrier();
 #ifdef V4H_GEMM2_STAMPS
         ++st_n;
 #endif
@@ -490,8 +493,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
       cv = nv; ti = n_ti; tj = n_tj; tz = n_tz;
       c_par ^= 1;
     }
-    if (half == 0 && two_barriers) slot_barrier();  // the slot in which half 1 multiplies its last stage
-    if (half == 0 || !seam_overlap) epilogue(p_ti, p_tj, p_tz);
+    epilogue(p_ti, p_tj, p_tz);
 #ifdef V4H_GEMM2_STAMPS
     __builtin_amdgcn_s_waitcnt(0xC07F);
     v4h_gemm2_stamp_buf[(blockIdx.x * 8 + wave) * G2_ST_N * G2_ST_K + lane] = reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[wave * G2_ST_N * G2_ST_K + lane];
@@ -499,6 +501,8 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
     return;
   }
 
+#ifdef V4H_ABLATIONS
+  // ------------------------------------------------------------------ lock-step schedule (ablation builds only)
   // prologue: three stages in flight, wait for the first
   int last_cnt, e1 = 0, e2 = 0;
   {
@@ -565,6 +569,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
     c_par ^= 1;
     init_acc(c_par);
   }
+#endif  // V4H_ABLATIONS
 }
 
 template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stream, const char* name) {
@@ -589,19 +594,10 @@ template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stre
   a.ntj = (a.J + C::BJ - 1) / C::BJ;
   long nblocks = a.nz == 1 ? (a.nti < 8 ? (long)a.nti * a.ntj : (long)((a.nti + 7) / 8) * 8 * a.ntj) : (long)a.nti * a.ntj * a.nz;
   if (nblocks > 256) nblocks = 256;  // one persistent workgroup per CU
-  // V4H_PP_FLAGS bit 1: the first form of the ping-pong schedule, a barrier after EVERY slot (the data only needs the one at the end of a stage: 3-7 % per
-  // call, +1.2 % steps/s, +4 % showers/s without the other); bit 0 (only meaningful with bit 1): both halves write a finished tile in the same slot.
-  static const int pp_flags = [] { const char* e = getenv("V4H_PP_FLAGS"); return e ? atoi(e) : 0; }();
-  a.sched_flags = pp_flags;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);
-    if (e != hipSuccess) {
-      v4h_set_error("%s: cannot reserve %zu bytes of LDS: %s", name, (size_t)C::LDS_BYTES, hipGetErrorString(e));
-      return V4H_ERR_HIP;
-    }
-    attr_set = true;
-  }
+  static DeviceOnce lds_attr;  // the attribute belongs to the function object of ONE device
+  if (int rc = lds_attr.ensure([&]() -> hipError_t {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);
+      }, name, "reserve the ring's LDS")) return rc;
 #ifdef V4H_GEMM2_STAMPS
   hipLaunchKernelGGL(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES + 2048, stream, a);
 #else

@@ -16,7 +16,8 @@ int gemm_wgrad_splitk(Mode m, int I, int J, int K);  // the split count the runt
 int gemm_wgrad_slab(Mode m, const GemmArgs& a, int splitk, float* slab, int* nz_out, hipStream_t s);  // partials [nz][I][J], plain stores
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s);  // out[k] += sum_z slab[z*n + k]
 
-void debug_set_gemm_cfg(int cfg, int cfg_wgrad);  // tile-shape tuning hook
+int select_contraction_kernel(int which);  // 0 automatic, 1 two-workgroup kernel everywhere, 2 ring kernel wherever eligible (all exact)
+int selected_contraction_kernel();
 
 // ---- attention (v4h_attention.hip) ----
 int attention_fwd(Mode m, const void* qkv, void* o, float* lse, int B, int T, int H, int DH, hipStream_t s);

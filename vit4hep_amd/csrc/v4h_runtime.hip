@@ -53,7 +53,6 @@ struct v4h_plan {
   // Linear both consume dY and are independent, so they run concurrently and fill each other's idle CUs / tile tails.
   // Fork/join with events only, so the caller's stream ordering (and graph capture) stays intact.
   mutable hipStream_t side = nullptr;
-  mutable hipStream_t side2 = nullptr;  // third queue for the head and the tail of a pass: chains of small, latency-bound kernels that are independent of each other
   mutable hipEvent_t ev[8] = {};
   mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable int evi = 0;
@@ -88,15 +87,6 @@ static int side_init(const v4h_plan& p) {
   else
     se = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
   if (se != hipSuccess) { v4h_set_error("cannot create side stream"); return V4H_ERR_HIP; }
-  // V4H_THIRD_QUEUE=1 (opt-in): a third queue (the remaining priority class) for the t_embedder chains at the two ends of a pass, +0.3-0.9 % steps/s
-  // on one rank.  NOT the default: as soon as a process group and its communication stream exist (every N > 1 run), the three classes no longer get a
-  // hardware queue each and the pass serialises - 126 instead of 216 steps/s on one rank with the collectives forced on.
-  const char* tq = getenv("V4H_THIRD_QUEUE");
-  if (tq && tq[0] == '1' && greatest != least) {
-    const int other = (pe && pe[0] == 'l') ? greatest : least;
-    if (hipStreamCreateWithPriority(&p.side2, hipStreamNonBlocking, other) != hipSuccess) p.side2 = nullptr;
-  }
-  if (!p.side2) p.side2 = p.side;
   // The events only order the two streams of this device against each other; nobody inspects them from the host, so recording one
   // needs no system-scope release (an L2 write-back + ~6 us bubble in front of the next kernel of the recording stream, 30 times per
   // step: 180.1 -> 182.8 steps/s).  The kernels' own agent-scope release at their end is what the other stream's kernels need.
@@ -443,7 +433,9 @@ static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, 
   // Split-K partial sums: plain coalesced stores into a slab + one reduce pass instead of sk-fold f32 atomics (which run
   // at ~1.3 TB/s at the memory side): faster, and the weight gradient is bitwise reproducible.
   if (sk > 1 && ldo == J && (size_t)sk * I * J * 4 <= slab_bytes(c.p) && (I * (long)J) % 4 == 0) {
-    float* slab = c.w.slab[s && s != c.s ? 1 : 0];
+    // one scratch slab per queue (main: 0, side: 1): calls on one stream are ordered, calls on the two streams never share a slab
+    V4H_CHECK_ARG(st == c.s || st == c.p.side, "wgrad: stream is neither the caller's nor the plan's side stream (no split-K scratch for it)");
+    float* slab = c.w.slab[st == c.s ? 0 : 1];
     int nz = 1;
     RUN(gemm_wgrad_slab(c.p.mode, a, sk, slab, &nz, st));
     return slab_reduce(slab, nz, (long)I * J, dW, st);
@@ -514,8 +506,8 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   if (fork) {
     RUN(side_wait_main(*p, c.s));
     cs = p->side;
-    ts = same_c ? cs : p->side2;  // (no c_embedder work to run beside: the extra hop between queues would only cost - 1271 vs 1280 showers/s)
-    RUN(stream_wait(*p, ts, c.s));
+    ts = cs;  // (a third queue for the t_embedder chain was worth +0.3-0.9 % on one rank and serialised the whole pass as soon as a process group's
+              //  communication stream existed - 126 instead of 216 steps/s: removed in round 3)
   }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
   char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
@@ -670,7 +662,6 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   layout(*p, B, true, (char*)ws, c.w);
   const WS& w = c.w;
   const Mode m = p->mode;
-  bool t_chain_forked = false;  // the t_embedder chain of the last stage went to the third queue: joined at the end
   const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
   RUN(side_init(*p));
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
@@ -832,15 +823,15 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       }
       if (ov && !batch_ada) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
-      // t_embedder: a chain of its own (third queue) - it only needs d cond, not the x_embedder / adaLN weight gradients queued on the side stream
-      hipStream_t st2 = ov ? p->side2 : c.s;
+      // t_embedder: on the side stream behind the x_embedder / adaLN weight gradients (it only needs d cond); every wgrad() there shares slab[1],
+      // which is safe because one stream orders them
+      hipStream_t st2 = ov ? p->side : c.s;
       if (ov) RUN(stream_wait(*p, st2, c.s));  // d cond ready
       RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B], st2));
       GemmArgs a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
       a.e.out = w.dh_small2; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
       RUN(gemm_dgrad(m, EPI_DSILU, a, st2));
       RUN(wgrad(c, w.dh_small2, D, D, w.temb, p->F, p->F, B, (float*)grads[P_T0W], p->F, (float*)grads[P_T0B], st2));
-      t_chain_forked = ov && st2 != p->side;
       // c_embedder
       RUN(wgrad(c, w.dcond, D, D, w.hc, D, D, B, (float*)grads[P_C2W], D, (float*)grads[P_C2B]));
       a = gargs(w.dcond, D, c.W(P_C2W), D, B, D, D);
@@ -863,7 +854,6 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
   // kernel is left reading a temporary the next call may overwrite.
   if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));
-  if (t_chain_forked) RUN(stream_wait(*p, c.s, p->side2));
   if (stage_last == depth + 1) RUN(stage_done(depth + 1, c.s));
   return V4H_OK;
 }
@@ -907,7 +897,8 @@ extern "C" int32_t v4h_rk4_combine(float* y, const float* k1, const float* k2, c
   return rk4_combine(y, k1, k2, k3, k4, h, n, (hipStream_t)s);
 }
 
-extern "C" void v4h_debug_set_gemm_cfg(int32_t cfg, int32_t cfg_wgrad) { debug_set_gemm_cfg(cfg, cfg_wgrad); }
+extern "C" int32_t v4h_select_contraction_kernel(int32_t which) { return select_contraction_kernel(which); }
+extern "C" int32_t v4h_selected_contraction_kernel(void) { return selected_contraction_kernel(); }
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t pks, const void* Q, int32_t ldq, int32_t qks, const float* bias, void* out,
@@ -932,6 +923,10 @@ extern "C" int32_t v4h_op_gemm_wgrad_splitk(int32_t mode, int32_t I, int32_t J, 
 extern "C" int32_t v4h_op_gemm_wgrad_slab(int32_t mode, const void* P, int32_t ldp, const void* Q, int32_t ldq, float* slab, float* out, int32_t I, int32_t J, int32_t K,
                                           int32_t splitk, float* colsum, void* s) {
   V4H_CHECK_ARG((mode == 0 || mode == 1) && P && Q && slab && out && splitk >= 1, "op_gemm_wgrad_slab: bad argument");
+  V4H_CHECK_ARG(I > 0 && J > 0 && K > 0 && ldp >= I && ldq >= J, "op_gemm_wgrad_slab: empty problem or row strides shorter than the rows (I=%d J=%d K=%d ldp=%d ldq=%d)", I, J, K, ldp, ldq);
+  // the reduction pass works on float4s and the partials of consecutive splits are I * J floats apart
+  V4H_CHECK_ARG(((long)I * J) % 4 == 0, "op_gemm_wgrad_slab: I * J = %ld must be a multiple of 4", (long)I * J);
+  V4H_CHECK_ARG(((uintptr_t)slab % 16) == 0 && ((uintptr_t)out % 16) == 0, "op_gemm_wgrad_slab: slab and out must be 16-byte aligned");
   GemmArgs a = gargs(P, ldp, Q, ldq, I, J, K);
   a.colsum = colsum;
   int nz = 0;

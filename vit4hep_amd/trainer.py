@@ -46,8 +46,11 @@ class CFMTrainer:
         self.step_count = 0
         self.group = group
         # The reference raises on a non-finite gradient norm BEFORE optimizer.step(), also without clipping (max_norm = inf; base_experiment.py:573-585).
-        # Here the update kernel skips such a step on the device and bumps a sticky counter; the host looks at it every `nonfinite_check_every`
-        # steps (one 4-byte read) and in check_finite(), raises the same error and rewinds step_count / the LR schedule by the skipped updates.
+        # Here the update kernel skips such a step on the device and bumps a sticky counter - and while that counter is non-zero it skips (and counts)
+        # EVERY later update too, so no update is ever applied with a shifted Adam / LR-schedule index.  The host looks at the counter every
+        # `nonfinite_check_every` steps (one 4-byte read) and in raise_if_nonfinite(), raises the same error and rewinds step_count by the skipped
+        # updates: parameters, moments and step index are then exactly those of the last finite step, as after the reference's raise.  (All ranks see
+        # the same all-reduced gradient norm, hence the same counter.)
         self.nonfinite_check_every = int(nonfinite_check_every)
         self._flatten()
 
