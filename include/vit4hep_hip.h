@@ -200,6 +200,13 @@ int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const 
  * operand is stored [k][idx].  out is `mode`-typed unless out_f32 != 0.  nn.Linear forward/dgrad/wgrad. */
 int32_t v4h_op_gemm(int32_t mode, const void* d_P, int32_t ldp, int32_t p_kstrided, const void* d_Q, int32_t ldq, int32_t q_kstrided, const float* d_bias,
                     void* d_out, int32_t ldo, int32_t out_f32, int32_t I, int32_t J, int32_t K, int32_t splitk, float* d_colsum, void* stream);
+/* fc1 of the block's MLP with nn.GELU(approximate="tanh") fused into the contraction (timm Mlp, nn/vit.py:312-322): h[i][j] = gelu(sum_k x[i][k] W[j][k] + b[j])
+ * (`mode`-typed, row stride ldh) and, when d_dh != NULL (training), the derivative gelu'(.) of the same pre-activation, which the backward multiplies in. */
+int32_t v4h_op_gemm_gelu(int32_t mode, const void* d_x, int32_t ldx, const void* d_W, int32_t ldw, const float* d_bias, void* d_h, int32_t ldh, void* d_dh,
+                         int32_t ld_dh, int32_t I, int32_t J, int32_t K, void* stream);
+/* input gradient of fc2 times the saved GELU derivative: out[i][j] = (sum_k dy[i][k] W[k][j]) * gelu_grad[i][j]   (W stored [K][J] as nn.Linear keeps it) */
+int32_t v4h_op_gemm_dgelu(int32_t mode, const void* d_dy, int32_t ld_dy, const void* d_W, int32_t ldw, const void* d_gelu_grad, int32_t ld_g, void* d_out,
+                          int32_t ldo, int32_t I, int32_t J, int32_t K, void* stream);
 /* Weight gradient as the backward pass computes it: out[i][j] += sum_k P[k][i] Q[k][j] (both operands token-major), split-K partials
  * into d_slab (f32, at least splitk * I * J elements) with plain stores, then one ordered reduction (bit-reproducible); optional
  * d_colsum[i] += sum_k P[k][i] (the bias gradient).  nn.Linear wgrad, reference nn/vit.py:416,420 + timm Mlp :317-322. */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "v4h_axpby": (_i32, [_vp, _vp, _vp, _f32, _f32, _i64, _vp]),
     "v4h_rk4_combine": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "v4h_op_gemm": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "v4h_op_gemm_gelu": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "v4h_op_gemm_dgelu": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "v4h_op_gemm_wgrad_slab": (_i32, [_i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "v4h_op_gemm_wgrad_splitk": (_i32, [_i32, _i32, _i32, _i32]),
     "v4h_op_attention_fwd": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -711,6 +711,12 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
   if (pend >= 0) store_dkv(pend);
 }
 
+}  // namespace
+#include "v4h_attention_dense.h"
+namespace {
+using v4h_dense::attn_fwd_dense_kernel;
+using v4h_dense::DenseImage;
+
 template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -736,6 +742,13 @@ template <typename T, int NW, int DHT = 80> int attn_fwd_launch(const void* qkv,
   V4H_CHECK_LAUNCH("attn_fwd");
   return V4H_OK;
 }
+template <int NT, int WPE, int NBUF> int attn_fwd_dense_launch(const void* qkv, void* o, float* lse, int Tn, int H, int nitems, float scale, int grid, hipStream_t s) {
+  const size_t lds = NBUF * 2 * (size_t)DenseImage<NT>::BYTES;
+  int rc = set_lds(attn_fwd_dense_kernel<NT, WPE, NBUF>, lds, "attn_fwd_dense");
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_fwd_dense_kernel<NT, WPE, NBUF>), dim3(grid), dim3(64 * NT), lds, s, (const bf16*)qkv, (bf16*)o, lse, Tn, H, nitems, scale);
+  return V4H_OK;
+}
 template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B, int Tn, int H, int DH, hipStream_t s) {
   if (DH == 32) {  // energy-model transformer (d_model 128, 4 heads; configs/model/cfm/cfm_ds2_energy.yaml), forward only
     V4H_CHECK_ARG(Tn <= 64, "attention: head_dim 32 is built for sequences of at most 64 tokens (got %d)", Tn);
@@ -744,6 +757,17 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
   V4H_CHECK_ARG(DH == 80, "attention: head_dim %d not built (80 = 480/6 for every shape-CFM config, 32 forward-only for the energy model)", DH);
   const int ntiles = (Tn + 15) / 16;
   if constexpr (sizeof(T) == 2) {
+    static const int dense = getenv("V4H_ATTN_DENSE") ? atoi(getenv("V4H_ATTN_DENSE")) : 1;  // A/B hook: 0 = round 2's persistent kernel
+    if (dense && Tn <= KC && ntiles >= 9 && (long)H * 80 * 2 * 3 * Tn < 0x7FFFFF00L) {  // 129..160 tokens: the instruction-lean, descriptor-addressed form
+      // (its key mask covers the LAST tile only, so the tile count must be ceil(T / 16); shorter sequences keep the kernels below)
+      const int nitems = B * H;
+      const float scale = 1.0f / sqrtf((float)DH);
+      const int rc = ntiles <= 9 ? attn_fwd_dense_launch<9, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, 256, s)
+                                 : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, 256, s);
+      if (rc) return rc;
+      V4H_CHECK_LAUNCH("attn_fwd_dense");
+      return V4H_OK;
+    }
     static const bool persist = !(getenv("V4H_ATTN_PERSIST") && getenv("V4H_ATTN_PERSIST")[0] == '0');
     if (persist && Tn <= KC && ntiles <= 9) {  // single key chunk: persistent, double-buffered K/V
       constexpr int NW = 9;

@@ -1,0 +1,240 @@
+// Single-chunk attention (sequences of at most 160 tokens: ds2 / LEMURS T = 135, ds1, CaloGAN), bf16, head_dim 80 - the instruction-lean forms of round 3.
+// Reference: nn/vit.py:425-451 (softmax(q k^T / sqrt(dh)) v per (batch, head), token-major qkv as the qkv Linear writes it).
+//
+// What round 2's counters said about the persistent kernels of v4h_attention.hip (profiles/r03_attn_counters.md): a wave executes ~710 vector + ~430 scalar
+// instructions per (batch, head) item around 55 MFMAs, the vector-issue port of the busiest SIMD (3 of the 9 waves) is ~70 % busy and every wave is parked
+// half of its life - the kernel is bound by instruction issue at 2.25 waves per SIMD, not by the matrix pipe (20 %), LDS (10 %) or memory.  So this form
+//   * spends ~190 vector instructions per item: scores stay raw (the softmax scale is folded into the exponent: p = exp2(s c - m c)), only the one key
+//     tile that can hold rows >= T is masked, the row maximum is 3-input maxima + two lane swaps, the row SUM comes out of the P V product itself (a sixth
+//     output tile against an all-ones operand: every lane then holds its row's sum, no lane exchange), the head_dim tail (80 = 2.5 x 32) is a K = 32 MFMA
+//     whose query-side operand is zero beyond head_dim (those lanes' loads lie outside the buffer descriptor), so the key side needs no mask - it reads on
+//     into the next image row, finite data times zero; the key tail of an odd tile count likewise has a zero half.  (A K = 16 MFMA for the two tails,
+//     v_mfma_f32_16x16x16_bf16 accumulating straight onto a 16x16x32 result, came out wrong in two of four accumulator registers whenever the compiler
+//     scheduled the pair back to back - found with tools/experiments/attn_debug2.py - so no K = 16 instruction is used.)
+//   * addresses everything per item through ONE buffer descriptor built from scalars (item base in SGPRs, per-lane offsets fixed for the whole kernel): no
+//     per-item 64-bit vector address arithmetic, rows >= T are dropped / zero-filled by the descriptor's bounds check instead of by predicates;
+//   * holds ONE pair of K / V images per workgroup (2 x 23 KB for 9 tiles) so that TWO workgroups share a CU: 18 waves (4-5 per SIMD instead of 3-2-2-2)
+//     - the DMA wait and the barrier of one workgroup are the other's compute time, and the SIMD imbalance of nine waves on four SIMDs averages out.
+#pragma once
+
+namespace v4h_dense {  // (a named namespace: the host stubs of two of these kernel instantiations were not emitted from an anonymous one)
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_;
+
+// exchange between the 16-lane rows (0<->1, 2<->3) / the 32-lane halves, then reduce: both copies hold the other side's value afterwards
+V4H_DEV float max_xor16(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+V4H_DEV float max_xor32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+V4H_DEV unsigned pack_bf16(float a, float b) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, b2{(bf16)a, (bf16)b});
+}
+// accumulator tiles (lane (c, g): row c, columns 4 g .. 4 g + 3 of a 16-column tile) -> lane-side operand of the next product
+V4H_DEV Frag<bf16> acc_pair_frag(f32x4 a0, f32x4 a1) {  // K = 32 step: k = 4 g + j (tile 0), 16 + 4 g + j (tile 1)   (= frag_from_acc)
+  const u32x4_ w{pack_bf16(a0[0], a0[1]), pack_bf16(a0[2], a0[3]), pack_bf16(a1[0], a1[1]), pack_bf16(a1[2], a1[3])};
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+V4H_DEV Frag<bf16> acc_half_frag(f32x4 a0) {  // the same with a zero second tile (odd tile count: 16 keys in the last K = 32 step)
+  const u32x4_ w{pack_bf16(a0[0], a0[1]), pack_bf16(a0[2], a0[3]), 0u, 0u};
+  Frag<bf16> f;
+  f.v = __builtin_bit_cast(bf16x8, w);
+  return f;
+}
+
+constexpr int AD_DH = 80, AD_ROWB = 160;  // head_dim, bytes per image row (dense)
+
+// Image of NT * 16 rows x 80 bf16 (dense 160-byte rows) filled by buffer_load ... lds: instruction `inst` writes bytes [inst * 1024, + 1024), lane `l` its 16-byte
+// unit u = inst * 64 + l = (row u / 10, chunk u % 10).  The source offset of a unit is fixed for the whole kernel (row * ld_bytes + chunk * 16, relative to the
+// item's q/k/v base in the descriptor); units of rows >= T lie beyond the descriptor's range and read as zero.
+template <int NT> struct DenseImage {
+  static constexpr int ROWS = NT * 16, UNITS = ROWS * 10, NI = (UNITS + 63) / 64, BYTES = NI * 1024, NPW = (NI + NT - 1) / NT;
+  unsigned voff[NPW];  // per DMA instruction of this wave (inst = wave + k * NT): the lane's source byte offset
+  V4H_DEV void init(int wave, int lane, int ld_bytes) {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int u = (wave + k * NT) * 64 + lane;
+      voff[k] = u < UNITS ? (unsigned)((u / 10) * ld_bytes + (u % 10) * 16) : 0x7FFFFF00u;
+    }
+  }
+  // (`add` = byte offset of the tensor's slice inside the descriptor, added to the vector offset: the scalar offset of a buffer instruction is not
+  //  part of the range check on every generation, and the range check is what zero-fills the rows >= T)
+  V4H_DEV void stage(__amdgpu_buffer_rsrc_t rsrc, char* img, unsigned add, int wave) const {
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int inst = wave + k * NT;
+      if (inst < NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (V4H_LDS void*)(img + inst * 1024), 16, voff[k] + add, 0, 0, 0);
+    }
+  }
+};
+
+// Persistent (batch, head) walk, XCD-aware (attn_item, v4h_attention.hip).  NT = query tiles = key tiles = waves (9: T <= 144, 10: T <= 160).
+template <int NT, int WPE, int NBUF> __global__ __launch_bounds__(64 * NT, WPE) void attn_fwd_dense_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                                                              float* __restrict__ lse, int Tn, int H, int nitems, float scale) {
+  using IMG = DenseImage<NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF x [K image | V image]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * AD_DH, ldb = 3 * D * 2;  // bytes between consecutive tokens of qkv
+  const int Bn = nitems / H;
+  // softmax in base 2 with the scale folded into the exponent
+  const float c2 = scale * 1.4426950408889634f;
+  constexpr bool ODD = (NT & 1) != 0;  // odd tile count: the last 16 keys are a K = 16 step of the P V product
+  constexpr int NKS = NT / 2;
+  // rows >= Tn of the last key tile: masked before the maximum (their scores are 0, from the zero rows of the image, not -inf)
+  bool dead[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dead[r] = (NT - 1) * 16 + 4 * g + r >= Tn;
+
+  IMG img;
+  img.init(wave, lane, ldb);
+  // (head_dim tail, d = 64 .. 95: lanes g >= 2 would hold d >= 80 - their offset lies outside every descriptor, so they load zeros)
+  const unsigned q_off = (unsigned)((wave * 16 + c) * ldb + 16 * g), q_tail = g < 2 ? (unsigned)((wave * 16 + c) * ldb + 128 + 16 * g) : 0x7FFFFF00u;
+  const unsigned o_off = (unsigned)((wave * 16 + c) * D * 2);
+  // images start from zeros: a unit beyond the sequence is never written by the DMA if the hardware drops (rather than zero-fills) out-of-range LDS loads
+  for (int i = tid * 16; i < NBUF * 2 * IMG::BYTES; i += 64 * NT * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  __syncthreads();
+  // one descriptor per item for its q, k, v: rows [0, T) of sample b, starting at head h's q slice; k and v are D and 2 D elements further
+  auto item_rsrc = [&](int it) {
+    const int b = it / H, h = it - b * H;
+    const bf16* ibase = qkv + ((size_t)b * Tn * 3 * D + h * AD_DH);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(ibase), 0, (Tn - 1) * ldb + 4 * D + AD_ROWB, 0x00020000);
+  };
+  auto stage_item = [&](__amdgpu_buffer_rsrc_t r, int buf) {
+    img.stage(r, smem + buf * 2 * IMG::BYTES, 2u * D, wave);
+    img.stage(r, smem + buf * 2 * IMG::BYTES + IMG::BYTES, 4u * D, wave);
+  };
+
+  Frag<bf16> ones;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) ones.v[r] = (bf16)1.0f;
+
+  // NBUF == 1: two workgroups per CU, each waits for its own images (the other one computes meanwhile).  NBUF == 2: one workgroup per CU, the next
+  // item's images and query rows are requested before the current item is computed (the memory system sees a continuous stream).
+  int it = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, 0, Bn, H));
+  u32x4_ q0n = {0u, 0u, 0u, 0u}, q1n = q0n, q2n = q0n;
+  if (NBUF == 2 && it >= 0) {
+    const __amdgpu_buffer_rsrc_t r0 = item_rsrc(it);
+    stage_item(r0, 0);
+    q0n = __builtin_amdgcn_raw_buffer_load_b128(r0, q_off, 0, 0);
+    q1n = __builtin_amdgcn_raw_buffer_load_b128(r0, q_off + 64, 0, 0);
+    q2n = __builtin_amdgcn_raw_buffer_load_b128(r0, q_tail, 0, 0);
+  }
+  for (int n = 0; it >= 0; ++n) {
+    const int b = it / H, h = it - b * H;
+    const int it_next = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H));
+    const int buf = NBUF == 2 ? (n & 1) : 0;
+    const bf16* sK = reinterpret_cast<const bf16*>(smem + buf * 2 * IMG::BYTES);
+    const bf16* sV = reinterpret_cast<const bf16*>(smem + buf * 2 * IMG::BYTES + IMG::BYTES);
+    Frag<bf16> xq0, xq1, xq2;
+    if constexpr (NBUF == 1) {
+      const __amdgpu_buffer_rsrc_t rq = item_rsrc(it);
+      if (n > 0) __syncthreads();  // every wave is done with the previous item's images
+      stage_item(rq, 0);
+      // this wave's 16 query rows (lane side): two K = 32 slabs and the tail of head_dim
+      const u32x4_ q0 = __builtin_amdgcn_raw_buffer_load_b128(rq, q_off, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rq, q_off + 64, 0, 0);
+      const u32x4_ q2 = __builtin_amdgcn_raw_buffer_load_b128(rq, q_tail, 0, 0);
+      xq0.v = __builtin_bit_cast(bf16x8, q0);
+      xq1.v = __builtin_bit_cast(bf16x8, q1);
+      xq2.v = __builtin_bit_cast(bf16x8, q2);
+      __syncthreads();  // (vmcnt(0) + barrier) the images have landed for every wave
+    } else {
+      xq0.v = __builtin_bit_cast(bf16x8, q0n);
+      xq1.v = __builtin_bit_cast(bf16x8, q1n);
+      xq2.v = __builtin_bit_cast(bf16x8, q2n);
+      __syncthreads();  // this item's images have landed (vmcnt(0)); everyone is done with the buffer the next request overwrites
+      if (it_next >= 0) {
+        const __amdgpu_buffer_rsrc_t rn = item_rsrc(it_next);
+        stage_item(rn, buf ^ 1);
+        q0n = __builtin_amdgcn_raw_buffer_load_b128(rn, q_off, 0, 0);
+        q1n = __builtin_amdgcn_raw_buffer_load_b128(rn, q_off + 64, 0, 0);
+        q2n = __builtin_amdgcn_raw_buffer_load_b128(rn, q_tail, 0, 0);
+      }
+    }
+
+    // ---- scores: p[jt][r] = q_c . k_(16 jt + 4 g + r), raw
+    f32x4 p[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      a = mma(frag_kcontig(sK, AD_DH, jt * 16, 0, lane), xq0, a);
+      a = mma(frag_kcontig(sK, AD_DH, jt * 16, 32, lane), xq1, a);
+      a = mma(frag_kcontig(sK, AD_DH, jt * 16, 64, lane), xq2, a);  // (lanes g >= 2 read the next row's first columns: multiplied by the zeros of xq2)
+      p[jt] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[NT - 1][r] = dead[r] ? -INFINITY : p[NT - 1][r];
+    float mx = p[0][0];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      mx = fmaxf(fmaxf(mx, p[jt][0]), p[jt][1]);  // (v_max3_f32)
+      mx = fmaxf(fmaxf(mx, p[jt][2]), p[jt][3]);
+    }
+    mx = max_xor32(max_xor16(mx));
+    const float m2 = mx * c2;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[jt][r] = __builtin_amdgcn_exp2f(fmaf(p[jt][r], c2, -m2));
+    // ---- o = P V, and the row sum of the bf16-rounded P as a sixth output tile
+    f32x4 oacc[6];
+#pragma unroll
+    for (int dt = 0; dt < 6; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const Frag<bf16> wf = acc_pair_frag(p[2 * ks], p[2 * ks + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) oacc[dt] = mma(frag_kstrided2(sV, AD_DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
+      oacc[5] = mma(ones, wf, oacc[5]);
+    }
+    if constexpr (ODD) {
+      const Frag<bf16> wf = acc_half_frag(p[NT - 1]);
+      const int q4 = (lane >> 2) & 3, p4 = lane & 3;
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) {
+        const bf16x4 lo = lds_tr_read(sV + ((NT - 1) * 16 + 4 * g + q4) * AD_DH + dt * 16 + 4 * p4);
+        Frag<bf16> zf;
+        zf.v = __builtin_shufflevector(lo, bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, 0, 1, 2, 3, 4, 5, 6, 7);
+        oacc[dt] = mma(zf, wf, oacc[dt]);
+      }
+      oacc[5] = mma(ones, wf, oacc[5]);
+    }
+    const float l = oacc[5][0];
+    const float inv = __builtin_amdgcn_rcpf(l);
+    // ---- store: 8 consecutive columns per lane (tile pairs exchanged between the 16-lane rows), rows >= T dropped by the descriptor
+    bf16* obase = o + ((size_t)b * Tn * D + h * AD_DH);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (Tn - 1) * D * 2 + AD_ROWB, 0x00020000);
+    const int ge = g & 1, gh = g >> 1;
+    // (normalise BEFORE the lane exchange: the exchange is inline assembly, and the wait states an MFMA result needs before a vector instruction
+    //  reads it are only inserted for instructions the compiler can see - read straight after the last MFMA, element 0 of a tile came out wrong)
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) oacc[dt] *= inv;
+#pragma unroll
+    for (int d = 0; d < 4; d += 2)
+      __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(swap_pair(oacc[d], oacc[d + 1])), ro, o_off + (unsigned)(((d + ge) * 16 + 8 * gh) * 2), 0, 0);
+    {
+      const u32x2_ w{pack_bf16(oacc[4][0], oacc[4][1]), pack_bf16(oacc[4][2], oacc[4][3])};
+      __builtin_amdgcn_raw_buffer_store_b64(w, ro, o_off + (unsigned)((64 + 4 * g) * 2), 0, 0);
+    }
+    const int q = wave * 16 + c;
+    if (lse != nullptr && g == 0 && q < Tn) lse[((size_t)b * H + h) * Tn + q] = mx * scale + __logf(l);
+    it = it_next;
+  }
+}
+
+// (explicit instantiations: used only through a launcher template, the host stubs of the NBUF = 1 forms were not emitted by this hipcc)
+#define V4H_DENSE_FWD(NT, WPE, NBUF) \
+  template __global__ void attn_fwd_dense_kernel<NT, WPE, NBUF>(const bf16* __restrict__, bf16* __restrict__, float* __restrict__, int, int, int, float);
+V4H_DENSE_FWD(9, 3, 2) V4H_DENSE_FWD(10, 3, 2)
+#undef V4H_DENSE_FWD
+
+}  // namespace v4h_dense

@@ -193,6 +193,41 @@ V4H_DEV float wave_max(float v) {
   return v;
 }
 
+// `s_waitcnt vmcnt(n)` for a wave-uniform n that is only known at run time (gfx9 has no register form of the instruction): a computed jump into a table of
+// 49 two-instruction entries - eight scalar instructions in all.  (Written as a C++ switch the compiler lowers it to a chain of some 200 scalar compares and
+// branches, about 450 clocks on the critical path of every K-step: tools/experiments/gemm2_stamps.py.)  n above 48 waits for 48: only ever conservative.
+// The jump arithmetic assumes 8 bytes per table entry and takes the distance from the s_getpc result to the table from the assembler (label
+// difference), and the .if below fails the BUILD if an assembler ever encodes an entry in another size.  s[92:93] (the jump target needs an aligned
+// pair, which an asm operand cannot be split into) is declared clobbered; the other scratch register is the compiler's choice.
+V4H_DEV void wait_vmcnt64(int n) {
+#define V4H_VM_ROW(k) "s_waitcnt vmcnt(" #k ")\n\ts_branch 1f\n\t"
+  unsigned t32;
+  asm volatile(
+      "s_min_u32 %0, %1, 48\n\t"
+      "s_lshl_b32 %0, %0, 3\n\t"
+      "s_getpc_b64 s[92:93]\n"
+      "3:\n\t"
+      "s_add_u32 %0, %0, 2f-3b\n\t"
+      "s_add_u32 s92, s92, %0\n\t"
+      "s_addc_u32 s93, s93, 0\n\t"
+      "s_setpc_b64 s[92:93]\n"
+      "2:\n\t"
+      V4H_VM_ROW(0) V4H_VM_ROW(1) V4H_VM_ROW(2) V4H_VM_ROW(3) V4H_VM_ROW(4) V4H_VM_ROW(5) V4H_VM_ROW(6) V4H_VM_ROW(7) V4H_VM_ROW(8) V4H_VM_ROW(9)
+      V4H_VM_ROW(10) V4H_VM_ROW(11) V4H_VM_ROW(12) V4H_VM_ROW(13) V4H_VM_ROW(14) V4H_VM_ROW(15) V4H_VM_ROW(16) V4H_VM_ROW(17) V4H_VM_ROW(18) V4H_VM_ROW(19)
+      V4H_VM_ROW(20) V4H_VM_ROW(21) V4H_VM_ROW(22) V4H_VM_ROW(23) V4H_VM_ROW(24) V4H_VM_ROW(25) V4H_VM_ROW(26) V4H_VM_ROW(27) V4H_VM_ROW(28) V4H_VM_ROW(29)
+      V4H_VM_ROW(30) V4H_VM_ROW(31) V4H_VM_ROW(32) V4H_VM_ROW(33) V4H_VM_ROW(34) V4H_VM_ROW(35) V4H_VM_ROW(36) V4H_VM_ROW(37) V4H_VM_ROW(38) V4H_VM_ROW(39)
+      V4H_VM_ROW(40) V4H_VM_ROW(41) V4H_VM_ROW(42) V4H_VM_ROW(43) V4H_VM_ROW(44) V4H_VM_ROW(45) V4H_VM_ROW(46) V4H_VM_ROW(47) V4H_VM_ROW(48)
+      "\n1:\n\t"
+      ".if (1b - 2b) != 49 * 8\n\t"
+      ".error \"wait_vmcnt64: a table entry is not 8 bytes\"\n\t"
+      ".endif"
+      : "=&s"(t32)
+      : "s"(n)
+      : "s92", "s93", "scc", "memory");
+#undef V4H_VM_ROW
+}
+
+
 // ---- host side ------------------------------------------------------------------------------------
 #define V4H_OK 0
 #define V4H_ERR_ARG 1

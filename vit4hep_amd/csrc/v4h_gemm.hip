@@ -6,6 +6,7 @@
 
 #include "v4h_ops.h"
 #include "v4h_gemm2.h"
+#include "v4h_gemm_small.h"
 
 namespace v4h {
 namespace {
@@ -35,6 +36,7 @@ int g_kernel = kernel_from_env();
 // Contraction classes on the ring kernel under KERNEL_AUTO (bits: 1 forward plain store, 2 forward GELU of the update step - two outputs, 4 dgrad
 // plain store, 8 dgrad DGELU, 16 split-K weight-gradient slabs, 32 forward GELU without the saved derivative - inference), wherever the shape is eligible.
 int g_pp = env_flag("V4H_GEMM2_PP", 53) & 63;
+int g_small = env_flag("V4H_GEMM_SMALL", 1);  // A/B hook: 0 = the tiled kernel also for the batch-row contractions
 
 #ifdef V4H_ABLATIONS
 #include "v4h_gemm_ablations.inc"
@@ -72,6 +74,10 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
   { int rc; if (ablation_fwd<T>(epi, a, s, rc)) return rc; }
 #endif
   if constexpr (sizeof(T) == 2) {
+    if (g_small && v4h_small::smallm_eligible(a)) {  // batch-row contractions (conditioning MLPs): the whole K extent in one round trip
+      if (epi == EPI_SILU) return v4h_small::smallm_launch<false, EPI_SILU>(a, s, "gemm_small/silu");
+      if (epi == EPI_COND_SUM) return v4h_small::smallm_launch<false, EPI_COND_SUM>(a, s, "gemm_small/cond_sum");
+    }
     if (epi == EPI_STORE && on_ring(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
     if (epi == EPI_GELU && on_ring(a, a.K, a.e.out != nullptr ? 2 : 32) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
   }
@@ -103,6 +109,7 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
   { int rc; if (ablation_dgrad<T>(epi, a, s, rc)) return rc; }
 #endif
   if constexpr (sizeof(T) == 2) {
+    if (g_small && epi == EPI_DSILU && v4h_small::smallm_eligible(a)) return v4h_small::smallm_launch<true, EPI_DSILU>(a, s, "gemm_small/dsilu");
     if (epi == EPI_STORE && on_ring(a, a.K, 4)) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
     if (epi == EPI_DGELU && on_ring(a, a.K, 8) && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");
   }

@@ -501,13 +501,17 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // The token path (to_patches, positional table, x_embedder) and the conditioning path (t/c embedders, adaLN table) are
   // independent chains of small launch-latency-bound kernels until the first block: they run side by side.
   RUN(side_init(*p));
-  const bool fork = g_overlap_wgrad;
-  hipStream_t cs = c.s, ts = c.s;  // streams of the conditioning path: c_embedder + sum + adaLN table / first half of the t_embedder
+  // Only the c_embedder (two batch-row contractions, independent of everything else) forks to the side stream; the rest of the conditioning path
+  // follows the token path on the MAIN stream.  With the whole-K kernel of v4h_gemm_small.h each of these launches is 5-7 us, less than one
+  // cross-stream hand-over (an event record + wait is about 10 us of latency for the waiter: profiles/r03_step_timeline.txt), so the former layout -
+  // whole conditioning chain on the side stream, joined before the first block - left the main stream idle for 80 us per forward.
+  // (A third queue for the t_embedder was worth +0.3-0.9 % on one rank and serialised the whole pass as soon as a process group's communication
+  // stream existed - 126 instead of 216 steps/s - and was removed in round 3.)
+  const bool fork = g_overlap_wgrad && !same_c;
+  hipStream_t cs = c.s;  // stream of the c_embedder
   if (fork) {
     RUN(side_wait_main(*p, c.s));
     cs = p->side;
-    ts = cs;  // (a third queue for the t_embedder chain was worth +0.3-0.9 % on one rank and serialised the whole pass as soon as a process group's
-              //  communication stream existed - 126 instead of 216 steps/s: removed in round 3)
   }
   // 1-3. to_patches, x_embedder + learnable positional embedding (nn/vit.py:193)
   char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
@@ -543,31 +547,30 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       a.e.out = w.cemb; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_C2B);  // (silu_c: overwritten below)
       RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
     }
-    RUN(timestep_embed(m, t, w.temb, B, p->F, ts));
+    RUN(timestep_embed(m, t, w.temb, B, p->F, c.s));
     a = gargs(w.temb, p->F, c.W(P_T0W), p->F, B, D, p->F);
     a.e.out = w.ht; a.e.ldo = D; a.e.out2 = w.ht_pre; a.e.ldo2 = D; a.e.bias = c.pf(P_T0B);
-    RUN(gemm_fwd(m, EPI_SILU, a, ts));
-    RUN(stream_wait(*p, cs, ts));  // h_t beside c_emb
+    RUN(gemm_fwd(m, EPI_SILU, a, c.s));
+    if (fork) RUN(main_wait_side(*p, c.s));  // c_emb (long finished)
     a = gargs(w.ht, D, c.W(P_T2W), D, B, D, D);
     a.e.out = w.cond; a.e.ldo = D; a.e.out2 = w.silu_c; a.e.ldo2 = D; a.e.bias = c.pf(P_T2B); a.e.resid = w.cemb; a.e.ld_resid = D;
-    RUN(gemm_fwd(m, EPI_COND_SUM, a, cs));
+    RUN(gemm_fwd(m, EPI_COND_SUM, a, c.s));
   }
   // 9. every adaLN modulation of the step (nn/vit.py:323-330, 345-348)
   const int ldm = p->ldmod();
   if (w.adaW) {  // one contraction for the whole table: (B, D) x (ldmod, D)^T - seven launches of 18 workgroups each were pure launch latency
     GemmArgs a = gargs(w.silu_c, D, w.adaW, D, B, ldm, D);
     a.e.out = w.mod_all; a.e.ldo = ldm; a.e.bias = w.adaB;
-    RUN(gemm_fwd(m, EPI_STORE_F32, a, cs));
+    RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
   } else {
     for (int i = 0; i <= p->depth; ++i) {
       const bool last = i == p->depth;
       const int J = last ? 2 * D : 6 * D;
       GemmArgs a = gargs(w.silu_c, D, c.W(last ? p->fin(F_ADAW) : p->blk(i, B_ADAW)), D, B, J, D);
       a.e.out = last ? w.modf : w.mod[i]; a.e.ldo = ldm; a.e.bias = c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB));
-      RUN(gemm_fwd(m, EPI_STORE_F32, a, cs));
+      RUN(gemm_fwd(m, EPI_STORE_F32, a, c.s));
     }
   }
-  if (fork) RUN(main_wait_side(*p, c.s));
   // 10. DiT blocks (nn/vit.py:327-333)
   static const bool ln_resid = !(getenv("V4H_LN_RESID") && getenv("V4H_LN_RESID")[0] == '0');  // A/B hook
   const bool fuse_resid = ln_resid && ln_resid_supported(D);
@@ -823,10 +826,9 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       }
       if (ov && !batch_ada) RUN(main_wait_mark(*p, S_ADA, c.s));  // d silu(cond) has contributions from every adaLN backward on the side stream
       RUN(silu_bwd(m, w.dsilu, w.cond, w.dcond, B * D, c.s));
-      // t_embedder: on the side stream behind the x_embedder / adaLN weight gradients (it only needs d cond); every wgrad() there shares slab[1],
-      // which is safe because one stream orders them
-      hipStream_t st2 = ov ? p->side : c.s;
-      if (ov) RUN(stream_wait(*p, st2, c.s));  // d cond ready
+      // t_embedder: on the main stream with the c_embedder (the side stream already carries the grouped adaLN and the x_embedder weight gradients,
+      // 110 of the stage's 250 us of launches: profiles/r03_step_timeline.txt)
+      hipStream_t st2 = c.s;
       RUN(wgrad(c, w.dcond, D, D, w.ht, D, D, B, (float*)grads[P_T2W], D, (float*)grads[P_T2B], st2));
       GemmArgs a = gargs(w.dcond, D, c.W(P_T2W), D, B, D, D);
       a.e.out = w.dh_small2; a.e.ldo = D; a.e.auxf = w.ht_pre; a.e.ld_auxf = D;
@@ -915,6 +917,20 @@ extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t
   }
   v4h_set_error("op_gemm: layout (P K-strided, Q K-contiguous) is not used on the path and not built");
   return V4H_ERR_UNSUPPORTED;
+}
+extern "C" int32_t v4h_op_gemm_gelu(int32_t mode, const void* x, int32_t ldx, const void* W, int32_t ldw, const float* bias, void* h, int32_t ldh, void* dh,
+                                    int32_t ld_dh, int32_t I, int32_t J, int32_t K, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && x && W && h, "op_gemm_gelu: bad argument");
+  GemmArgs a = gargs(x, ldx, W, ldw, I, J, K);
+  a.e.out = dh; a.e.ldo = dh ? ld_dh : ldh; a.e.out2 = h; a.e.ldo2 = ldh; a.e.bias = bias;
+  return gemm_fwd((Mode)mode, EPI_GELU, a, (hipStream_t)s);
+}
+extern "C" int32_t v4h_op_gemm_dgelu(int32_t mode, const void* dy, int32_t ld_dy, const void* W, int32_t ldw, const void* gelu_grad, int32_t ld_g, void* out,
+                                     int32_t ldo, int32_t I, int32_t J, int32_t K, void* s) {
+  V4H_CHECK_ARG((mode == 0 || mode == 1) && dy && W && gelu_grad && out, "op_gemm_dgelu: bad argument");
+  GemmArgs a = gargs(dy, ld_dy, W, ldw, I, J, K);
+  a.e.out = out; a.e.ldo = ldo; a.e.aux = gelu_grad; a.e.ld_aux = ld_g;
+  return gemm_dgrad((Mode)mode, EPI_DGELU, a, (hipStream_t)s);
 }
 extern "C" int32_t v4h_op_gemm_wgrad_splitk(int32_t mode, int32_t I, int32_t J, int32_t K) {
   if ((mode != 0 && mode != 1) || I <= 0 || J <= 0 || K <= 0) return 1;
