@@ -136,6 +136,9 @@ template <typename T> int wgrad_t(const GemmArgs& a, int splitk, hipStream_t s) 
 #ifdef V4H_ABLATIONS
   { int rc; if (ablation_wgrad<T>(a, splitk, s, rc)) return rc; }
 #endif
+  if constexpr (sizeof(T) == 2) {  // over B tokens only (embedder MLPs): whole K in one round trip, plain read-modify-write instead of atomics
+    if (g_small && splitk <= 1 && v4h_small::smallk_wgrad_eligible(a)) return v4h_small::smallk_wgrad_launch(a, s);
+  }
   // tile shape: a plateau (profiles/r02_wgrad_tile_sweep.txt: 160x96, 128x160, 160x160, 96x160 within 4 % of each other at the split the runtime uses)
   return v4h_gemm_launch<GemmCfg<T, T, true, true, 160, 96, bk_of<T>(), 2, 2, EPI_ATOMIC_F32, true>>(a, splitk, s, "gemm_wgrad");
 }

@@ -10,6 +10,58 @@ namespace v4h_small {
 
 constexpr int SM_BI = 64, SM_BJ = 32, SM_KMAX = 512, SM_NT = 256;
 
+// The same idea for the weight gradients of those Linears, dW[i][j] += sum_t dY[t][i] X[t][j] over only B tokens (both operands K-strided, whole K in LDS,
+// no K split: every output element has ONE writer, so the accumulation is a plain read-modify-write; bias gradient = column sums of dY by the j-tile 0).
+__global__ __launch_bounds__(SM_NT) void v4h_smallk_wgrad_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [P image: K x 64 | Q image: K x 32]
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntj = a.J / SM_BJ;
+  const int ti = blockIdx.x / ntj, tj = blockIdx.x - ti * ntj;
+  const int i0 = ti * SM_BI, j0 = tj * SM_BJ, K = a.K;
+  const bf16* gP = reinterpret_cast<const bf16*>(a.P);
+  const bf16* gQ = reinterpret_cast<const bf16*>(a.Q);
+  char* iP = smem;
+  char* iQ = smem + K * SM_BI * 2;
+  for (int u0 = wave * 64; u0 < K * 8; u0 += SM_NT) {  // P[k][i0 .. i0 + 63]: 8 chunks per row; columns beyond I from the zero page
+    const int u = u0 + lane, r = u >> 3, ch = u & 7;
+    const void* src = (i0 + ch * 8 + 8 <= a.I) ? (const void*)(gP + (size_t)r * a.ldp + i0 + ch * 8) : (const void*)v4h_zero_page;
+    dma16(src, iP + u0 * 16);
+  }
+  for (int u0 = wave * 64; u0 < K * 4; u0 += SM_NT) {
+    const int u = u0 + lane, r = u >> 2, ch = u & 3;
+    dma16(gQ + (size_t)r * a.ldq + j0 + ch * 8, iQ + u0 * 16);
+  }
+  __syncthreads();
+  const bf16* sP = reinterpret_cast<const bf16*>(iP);
+  const bf16* sQ = reinterpret_cast<const bf16*>(iQ);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float cs = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    const Frag<bf16> pf = frag_kstrided(sP, SM_BI, k0, wave * 16, lane);
+    acc0 = mma(frag_kstrided(sQ, SM_BJ, k0, 0, lane), pf, acc0);
+    acc1 = mma(frag_kstrided(sQ, SM_BJ, k0, 16, lane), pf, acc1);
+    if (tj == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) cs += (float)pf.v[jj];
+    }
+  }
+  acc0 *= 1.0f;
+  acc1 *= 1.0f;
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
+  const f32x8 v = swap_pair(acc0, acc1);
+  const int i = i0 + wave * 16 + c, j = j0 + (g & 1) * 16 + (g >> 1) * 8;
+  if (i < a.I) {
+    float* o = reinterpret_cast<float*>(a.e.out) + (size_t)i * a.e.ldo + j;
+    store8(o, add8(load8(o), v));
+  }
+  if (tj == 0 && a.colsum != nullptr) {
+    cs += __shfl_xor(cs, 16, 64);
+    cs += __shfl_xor(cs, 32, 64);
+    if (g == 0 && i < a.I) a.colsum[i] += cs;
+  }
+}
+
 template <bool QKS, int EPI> __global__ __launch_bounds__(SM_NT) void v4h_smallm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [P image: 64 rows x K | Q image: 32 x K (K-contiguous) or K x 32 (K-strided)]
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -93,6 +145,20 @@ template <bool QKS, int EPI> int smallm_launch(const GemmArgs& a, hipStream_t s,
   const int grid = ((a.I + SM_BI - 1) / SM_BI) * (a.J / SM_BJ);
   hipLaunchKernelGGL((v4h_smallm_kernel<QKS, EPI>), dim3(grid), dim3(SM_NT), lds, s, a);
   V4H_CHECK_LAUNCH(name);
+  return V4H_OK;
+}
+inline bool smallk_wgrad_eligible(const GemmArgs& a) {
+  return a.K <= SM_KMAX && a.K % 32 == 0 && a.J % SM_BJ == 0 && a.I % 8 == 0 && a.ldp % 8 == 0 && a.ldq % 8 == 0 && a.e.ldo % 4 == 0 && a.e.group_rows == 0 &&
+         ((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.e.out % 16) == 0;
+}
+inline int smallk_wgrad_launch(const GemmArgs& a, hipStream_t s) {
+  static DeviceOnce lds_attr;
+  if (int rc = lds_attr.ensure([&]() -> hipError_t {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_smallk_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (SM_BI + SM_BJ) * SM_KMAX * 2);
+      }, "gemm_small/wgrad", "reserve the LDS of the tile")) return rc;
+  const int grid = ((a.I + SM_BI - 1) / SM_BI) * (a.J / SM_BJ);
+  hipLaunchKernelGGL(v4h_smallk_wgrad_kernel, dim3(grid), dim3(SM_NT), (size_t)(SM_BI + SM_BJ) * a.K * 2, s, a);
+  V4H_CHECK_LAUNCH("gemm_small/wgrad");
   return V4H_OK;
 }
 // (explicit instantiations: see v4h_attention_dense.h - host stubs of kernel templates reached only through a launcher template can go missing)
