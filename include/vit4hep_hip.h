@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 7
+#define V4H_ABI_VERSION 8
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -237,6 +237,15 @@ int32_t v4h_op_pos_embed(const v4h_plan* plan, const float* d_freqs, float* d_pe
    other values are ignored with a message on stderr. */
 int32_t v4h_select_contraction_kernel(int32_t which);
 int32_t v4h_selected_contraction_kernel(void);
+
+/* Leave n compute units (a multiple of 8 in [0, 64]; default 0) to a kernel of another library that runs beside the step - RCCL's ring kernels under
+   DistributedDataParallel-style gradient all-reduce (experiments/base_experiment.py:161-167).  The contraction and single-chunk attention kernels
+   launch ONE grid of persistent workgroups that each own a CU's whole LDS; with n reserved they launch 256 - n of them and the tile walk
+   redistributes, instead of 256 of which those aimed at the CUs the communication kernel occupies wait for the rest of the grid to retire.  Changes
+   scheduling only: every result is bit-identical for every n.  Process-global, read at launch time.  vit4hep_amd.parallel sets it when gradient
+   collectives are enabled (profiles/r03_comm_interference.md). */
+int32_t v4h_reserve_compute_units(int32_t n);
+int32_t v4h_reserved_compute_units(void);
 
 #ifdef __cplusplus
 }

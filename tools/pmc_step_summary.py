@@ -57,7 +57,7 @@ def load(name):
     if not f:
         return per, dur, calls
     seen = set()
-    for r in csv.DictReader(open(f[0])):
+    for r in csv.DictReader(open(max(f, key=os.path.getmtime))):
         k = short(r["Kernel_Name"])
         per[r["Counter_Name"]][k] += float(r["Counter_Value"])
         key = (r.get("Dispatch_Id"), r["Counter_Name"])
@@ -68,18 +68,65 @@ def load(name):
     return per, dur, calls
 
 
-fetch, _, _ = load("FETCH_SIZE")
+fetch, _, fcalls = load("FETCH_SIZE")
 write, _, _ = load("WRITE_SIZE")
+rq, _, _ = load("TCC_EA0_RDREQ_sum+TCC_EA0_RDREQ_32B_sum+TCC_EA0_RDREQ_64B_sum+TCC_EA0_RDREQ_128B_sum")
+
+
+def exact_fetch(k):
+    """bytes fetched by kernel k from the read requests by size class (32 / 64 / 128 bytes): what FETCH_SIZE would be if it priced each request at its size"""
+    n, n32, n64, n128 = (rq[c].get(k, 0.0) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+    if n == 0:
+        return None
+    other = max(n - n32 - n64 - n128, 0.0)  # requests in no size class (none seen so far): priced at 64 bytes like FETCH_SIZE does
+    return 32 * n32 + 64 * n64 + 128 * n128 + 64 * other
+
+
+# Algorithmic HBM bytes per call of the ds2 bs = 128 update step (BT = 17280 tokens, D = 480, M = 1920, bf16 activations, f32 residual stream): every
+# operand read once, every result written once, with the activation-materialising structure of the path (each Linear writes its output).
+BT, D, M = 17280, 480, 1920
+ALGO = {  # short kernel name -> (read MB per call, written MB per call, what)
+    "ln_modulate_fwd8_kernel": ((BT * D * 6) / 1e6, (BT * D * 6) / 1e6, "x f32 + y bf16 -> x' f32 + u bf16"),
+    "ln_modulate_bwd8_kernel": ((BT * D * 12) / 1e6, (BT * D * 6) / 1e6, "du bf16 + x f32 + dx f32 + y bf16 -> dx f32 + dy bf16"),
+    "attn_fwd_dense_kernel": ((BT * 3 * D * 2) / 1e6, (BT * D * 2) / 1e6, "qkv -> o"),
+    "attn_bwd_fused_kernel": ((BT * 5 * D * 2) / 1e6, (BT * 3 * D * 2) / 1e6, "qkv + o + dO -> dqkv"),
+    "adamw_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),
+    "gemm<bf16,fwd,128x160x64,GELU>": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "u2 + W -> h + gelu'"),
+    "gemm<bf16,dgrad,128x160x64,DGELU>": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "dy + W + gelu' -> dh"),
+    "gemm2<bf16,fwd,256x160x64,STORE,ping-pong>": ((BT * (D + D + M) * 2 + (3 * D * D + D * D + D * M) * 2) / 3e6, (BT * (3 * D + D + D) * 2) / 3e6, "mean of qkv, proj, fc2"),
+    "gemm2<bf16,dgrad,256x160x64,STORE,ping-pong>": ((BT * (3 * D + D + M) * 2 + (3 * D * D + D * D + D * M) * 2) / 3e6, (BT * 3 * D * 2) / 3e6, "mean of d qkv, d proj, d fc1"),
+    "gemm2<bf16,wgrad,256x160x64,SLAB_F32,colsum,ping-pong>": ((BT * ((3 * D + D) + (M + D) + (D + M)) * 2) / 3e6, (8 * (3 * D * D + 2 * D * M) * 4) / 3e6, "mean of qkv, fc1, fc2: dY + X -> 8 f32 slabs"),
+}
+
 tot_f = sum(fetch["FETCH_SIZE"].values()) * 1024 / steps
 tot_w = sum(write["WRITE_SIZE"].values()) * 1024 / steps
-print(f"HBM traffic per update step: FETCH_SIZE raw {tot_f/1e9:.3f} GB (x2 for 16-B/lane streams = {2*tot_f/1e9:.3f} GB), WRITE_SIZE {tot_w/1e9:.3f} GB  ->  {(2*tot_f+tot_w)/1e9:.3f} GB/step")
+tot_x = sum(v for v in (exact_fetch(k) for k in fetch["FETCH_SIZE"]) if v) / steps
+print(f"HBM traffic per update step: FETCH_SIZE raw {tot_f/1e9:.3f} GB (x2 = {2*tot_f/1e9:.3f} GB: FETCH_SIZE prices every read request at 64 bytes, the requests are 128 bytes - "
+      f"tools/experiments/fetch_calib.hip; priced by size class: {tot_x/1e9:.3f} GB), WRITE_SIZE {tot_w/1e9:.3f} GB  ->  {(2*tot_f+tot_w)/1e9:.3f} GB/step")
+print("\naudit: algorithmic bytes per call next to the counters (fetched = 2 x FETCH_SIZE, [by request size class]; written = WRITE_SIZE)")
+print(f"{'kernel':60s} {'calls':>5s} {'algo read':>10s} {'fetched':>9s} {'[sized]':>9s} {'ratio':>6s} {'algo write':>10s} {'written':>9s} {'ratio':>6s}  what")
+per_kernel = {}
+for k in sorted(fetch["FETCH_SIZE"], key=lambda k: -(2 * fetch["FETCH_SIZE"][k] + write["WRITE_SIZE"].get(k, 0.0))):
+    f_mb = 2 * fetch["FETCH_SIZE"][k] * 1024 / 1e6 / steps
+    w_mb = write["WRITE_SIZE"].get(k, 0.0) * 1024 / 1e6 / steps
+    per_kernel[k] = {"fetched_MB_per_step": round(f_mb, 1), "written_MB_per_step": round(w_mb, 1)}
+    a = next((v for kk, v in ALGO.items() if kk in k), None)
+    ncalls = int(round(fcalls[k] / steps))
+    if a is None or f_mb + w_mb < 50 or ncalls == 0:
+        continue
+    xf = exact_fetch(k)
+    per_kernel[k].update({"calls_per_step": ncalls, "algorithmic_read_MB_per_call": round(a[0], 1), "algorithmic_written_MB_per_call": round(a[1], 1)})
+    print(f"{k[:60]:60s} {ncalls:5d} {a[0]:10.1f} {f_mb/ncalls:9.1f} {(xf/1e6/steps/ncalls if xf else float('nan')):9.1f} {f_mb/ncalls/a[0]:6.2f} {a[1]:10.1f} {w_mb/ncalls:9.1f} {w_mb/ncalls/a[1]:6.2f}  {a[2]}")
 if tot_f > 0 and tot_w > 0:
     from vit4hep_amd.build import kernel_digest as _digest
 
     path = "profiles/step_hbm_traffic.json"
     rec = json.load(open(path)) if os.path.exists(path) else {}
-    rec["ds2/bf16"] = {"bytes_per_step": 2 * tot_f + tot_w, "fetch_size_raw": tot_f, "write_size": tot_w, "kernel_digest": _digest(), "steps_profiled": steps,
-                       "how": "tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py; FETCH doubled per MI355X_MICROARCH.md"}
+    rec["ds2/bf16"] = {"bytes_per_step": 2 * tot_f + tot_w, "fetch_size_raw": tot_f, "fetch_by_request_size": tot_x, "write_size": tot_w, "kernel_digest": _digest(),
+                       "steps_profiled": steps, "per_kernel": per_kernel,
+                       "how": "tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ by size class (separate passes) -- python3 "
+                              "bench.py; FETCH_SIZE doubled: it prices each (128-byte) read request at 64 bytes - calibrated on known byte counts for every access "
+                              "shape of the path with tools/experiments/fetch_calib.hip (profiles/r03_fetch_size_calibration.md)"}
     json.dump(rec, open(path, "w"), indent=1)
     print(f"wrote {path}")
 

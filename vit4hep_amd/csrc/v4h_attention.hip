@@ -762,8 +762,8 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
       // (its key mask covers the LAST tile only, so the tile count must be ceil(T / 16); shorter sequences keep the kernels below)
       const int nitems = B * H;
       const float scale = 1.0f / sqrtf((float)DH);
-      const int rc = ntiles <= 9 ? attn_fwd_dense_launch<9, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, 256, s)
-                                 : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, 256, s);
+      const int rc = ntiles <= 9 ? attn_fwd_dense_launch<9, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, v4h_compute_units(), s)
+                                 : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, v4h_compute_units(), s);
       if (rc) return rc;
       V4H_CHECK_LAUNCH("attn_fwd_dense");
       return V4H_OK;
@@ -775,7 +775,7 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
       int rc = set_lds(attn_fwd_persist_kernel<T, 80, NW>, lds, "attn_fwd_persist");
       if (rc) return rc;
       const int nitems = B * H;
-      hipLaunchKernelGGL((attn_fwd_persist_kernel<T, 80, NW>), dim3(256), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, nitems,
+      hipLaunchKernelGGL((attn_fwd_persist_kernel<T, 80, NW>), dim3(v4h_compute_units()), dim3(64 * NW), lds, s, (const T*)qkv, (T*)o, lse, Tn, H, nitems,
                          1.0f / sqrtf((float)DH));
       V4H_CHECK_LAUNCH("attn_fwd_persist");
       return V4H_OK;
@@ -815,7 +815,7 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
       int rc = set_lds(attn_bwd_fused_kernel<T, 80, NW>, lds, "attn_bwd_fused");
       if (rc) return rc;
       const int nitems = B * H;
-      hipLaunchKernelGGL((attn_bwd_fused_kernel<T, 80, NW>), dim3(256), dim3(64 * NW), lds, s, (const T*)qkv, (const T*)o, (const T*)dout, lse,
+      hipLaunchKernelGGL((attn_bwd_fused_kernel<T, 80, NW>), dim3(v4h_compute_units()), dim3(64 * NW), lds, s, (const T*)qkv, (const T*)o, (const T*)dout, lse,
                          (T*)dqkv, Tn, H, nitems, 1.0f / sqrtf((float)DH));
       V4H_CHECK_LAUNCH("attn_bwd_fused");
       return V4H_OK;

@@ -251,6 +251,15 @@ void v4h_set_error(const char* fmt, ...);
     }                                                                     \
   } while (0)
 
+// Compute units the persistent kernels size their grids for.  The contraction kernels and the single-chunk attention kernels launch one (or two)
+// workgroups per CU that own the CU's whole LDS and walk their tiles; a communication kernel (RCCL's ring, 8-16 workgroups with LDS of their own) that
+// sits on some CUs while such a grid is launched keeps the workgroups meant for those CUs waiting until another workgroup of the SAME grid retires, i.e.
+// until the end - the kernel then takes up to twice as long.  Under a process group the host therefore reserves CUs (v4h_reserve_compute_units) and the
+// grids shrink to 256 - reserved: the tile walk redistributes, nothing waits.  A multiple of 8 keeps workgroup id % 8 == XCD.  Measured in
+// profiles/r03_comm_interference.md.
+extern std::atomic<int> v4h_reserved_cus;
+inline int v4h_compute_units() { return 256 - v4h_reserved_cus.load(std::memory_order_relaxed); }
+
 // A per-function attribute (hipFuncSetAttribute: maximum dynamic LDS) belongs to the function object of the CURRENT device, so "done once" is
 // remembered per device ordinal, not per process: one process may drive several GPUs (_lib.on_device).  Setting it twice is harmless, so two
 // threads that race to the first launch both set it and both record it.

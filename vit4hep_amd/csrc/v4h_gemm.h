@@ -933,7 +933,7 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
   V4H_CHECK_ARG(nblocks < (1L << 31), "%s: grid too large", name);
   if (a.nz == 1) {  // persistent workgroups: as many as are co-resident (256 CUs x workgroups per CU by LDS), a multiple of 8
     const long per_cu = (160 * 1024) / (long)C::LDS_BYTES > 0 ? (160 * 1024) / (long)C::LDS_BYTES : 1;
-    const long resident = 256 * (per_cu > 2 ? 2 : per_cu);
+    const long resident = v4h_compute_units() * (per_cu > 2 ? 2 : per_cu);
     if (nblocks > resident) nblocks = resident;
   }
   dim3 grid((unsigned)nblocks);

@@ -561,7 +561,7 @@ template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stre
   a.nti = (a.I + C::BI - 1) / C::BI;
   a.ntj = (a.J + C::BJ - 1) / C::BJ;
   long nblocks = a.nz == 1 ? (a.nti < 8 ? (long)a.nti * a.ntj : (long)((a.nti + 7) / 8) * 8 * a.ntj) : (long)a.nti * a.ntj * a.nz;
-  if (nblocks > 256) nblocks = 256;  // one persistent workgroup per CU
+  if (nblocks > v4h_compute_units()) nblocks = v4h_compute_units();  // one persistent workgroup per CU (minus the CUs left to a communication kernel)
   static DeviceOnce lds_attr;  // the attribute belongs to the function object of ONE device
   if (int rc = lds_attr.ensure([&]() -> hipError_t {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);

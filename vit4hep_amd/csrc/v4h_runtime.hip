@@ -902,6 +902,14 @@ extern "C" int32_t v4h_rk4_combine(float* y, const float* k1, const float* k2, c
 extern "C" int32_t v4h_select_contraction_kernel(int32_t which) { return select_contraction_kernel(which); }
 extern "C" int32_t v4h_selected_contraction_kernel(void) { return selected_contraction_kernel(); }
 
+std::atomic<int> v4h_reserved_cus{0};
+extern "C" int32_t v4h_reserve_compute_units(int32_t n) {
+  V4H_CHECK_ARG(n >= 0 && n <= 64 && n % 8 == 0, "reserve_compute_units: %d is not a multiple of 8 in [0, 64]", n);
+  v4h_reserved_cus.store(n, std::memory_order_relaxed);
+  return V4H_OK;
+}
+extern "C" int32_t v4h_reserved_compute_units(void) { return v4h_reserved_cus.load(std::memory_order_relaxed); }
+
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t pks, const void* Q, int32_t ldq, int32_t qks, const float* bias, void* out,
                                int32_t ldo, int32_t out_f32, int32_t I, int32_t J, int32_t K, int32_t splitk, float* colsum, void* s) {
