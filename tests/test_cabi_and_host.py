@@ -56,6 +56,22 @@ def test_product_library_contains_no_ablation_kernels_and_refuses_to_select_one(
         assert ("ignored" in r.stderr) == (env_val in ("3", "10")), r.stderr
 
 
+def test_compute_unit_reservation_accepts_only_whole_xcd_rows():
+    """v4h_reserve_compute_units: the CUs the persistent grids leave to a communication kernel - a multiple of 8 (workgroup id % 8 must stay the XCD)
+    in [0, 64]; anything else is refused and leaves the setting unchanged."""
+    lib = _lib.load()
+    assert lib.v4h_reserved_compute_units() == 0
+    try:
+        for bad in (-8, 4, 12, 72, 256):
+            assert lib.v4h_reserve_compute_units(bad) == 1  # V4H_ERR_ARG
+            assert lib.v4h_reserved_compute_units() == 0
+        for ok in (16, 64, 8, 0):
+            assert lib.v4h_reserve_compute_units(ok) == 0
+            assert lib.v4h_reserved_compute_units() == ok
+    finally:
+        lib.v4h_reserve_compute_units(0)
+
+
 def test_plan_inventory_matches_reference_state_dict():
     for cfg in (O.ds2(6), O.ds3(6), O.ds2(2)):
         plan = _lib.Plan(cfg.shape, cfg.patch_shape, cfg.condition_dim, cfg.hidden_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden)

@@ -119,3 +119,35 @@ def test_single_chunk_attention_with_several_items_per_workgroup(B, T):
     p = torch.softmax(4.0 * torch.arange(T, device=U.DEV).float() / 16 / dh**0.5, 0)
     want = torch.zeros(dh, device=U.DEV).index_add_(0, torch.arange(T, device=U.DEV) % dh, p)
     assert float((o.float().reshape(B, T, H, dh) - want).abs().max()) < 4e-3
+
+
+def test_reserving_compute_units_changes_no_result():
+    """v4h_reserve_compute_units(n) shrinks the persistent grids (contractions on both kernels, single-chunk attention forward and backward) to 256 - n
+    workgroups; the tile walk redistributes and no value may change.  Loss and every gradient of an update step at n = 0, 0, 16, 64."""
+    lib = _lib.load()
+    cfg = O.ds2(2)
+    fill = O.golden_fill(cfg)
+    x, c, g = O.synthetic_batch(cfg, 24, 5)
+    t, x0 = O.synthetic_noise(cfg, 24, g)
+    outs = []
+    try:
+        for n in (0, 0, 16, 64):
+            _lib.check(lib.v4h_reserve_compute_units(n), "reserve")
+            model = U.build_models(cfg, "bf16", fill)
+            loss = model._loss_from_noise(x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV))
+            loss.backward()
+            outs.append({"loss": loss.detach().clone(), **{k: v.clone() for k, v in U.named_grads(model).items()}})
+    finally:
+        lib.v4h_reserve_compute_units(0)
+    # The token-stream contractions and attention are deterministic; the bias gradients (column sums), what hangs off the conditioning path and the loss
+    # are summed with f32 atomics, whose order differs from run to run whatever n is: those are held to rounding noise instead.
+    stream = [k for k in outs[0] if k.startswith("blocks.") and (".attn." in k or ".mlp." in k) and k.endswith(".weight")]
+    assert len(stream) == 8
+    for k in stream:
+        assert torch.equal(outs[0][k], outs[1][k]), k  # (the premise: deterministic at fixed n)
+    for o in outs[2:]:
+        for k, v in o.items():
+            if k in stream:
+                assert torch.equal(v, outs[0][k]), k
+            else:
+                assert U.rms_err(v, outs[0][k]) < 1e-3, (k, U.rms_err(v, outs[0][k]))

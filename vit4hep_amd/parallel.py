@@ -37,7 +37,11 @@ class BucketReducer:
         self.group = group
         self.pending = []
         self.cuda = flat.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        # A HIGH-PRIORITY stream: HIP multiplexes ordinary streams onto a few hardware queues, and a communication stream that lands on the queue of the
+        # compute stream runs its collectives only after everything enqueued there before it - i.e. after the whole backward pass, which is enqueued as one
+        # library call (measured: every bucket ran after the last backward kernel, profiles/r03_comm_interference.md).  Priority streams have hardware
+        # queues of their own, and a collective's few workgroups should win CUs ahead of the next contraction kernel anyway.
+        self.comm_stream = torch.cuda.Stream(device=flat.device, priority=-1) if self.cuda else None
 
     def reduce_slice(self, lo: int, hi: int):
         """Call right after the kernels producing flat[lo:hi] were enqueued on the current stream."""
@@ -69,8 +73,10 @@ class BucketReducer:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Make the current stream (or the host, on CPU) wait for every outstanding bucket."""
-        for w in self.pending:
+        """Make the current stream (or the host, on CPU) wait for every outstanding bucket.  On the GPU the buckets of one communicator complete in
+        issue order on one stream, so the current stream waits for the LAST one only: each wait is a barrier packet in the compute queue, and eight of them
+        in a row at the end of the backward cost 2 % of the step (profiles/r03_comm_interference.md)."""
+        for w in (self.pending[-1:] if self.cuda else self.pending):
             w.wait()
         self.pending = []
 
