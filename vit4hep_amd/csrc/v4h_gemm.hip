@@ -150,7 +150,8 @@ int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk) { 
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s) { return m == MODE_BF16 ? wgrad_t<bf16>(a, splitk, s) : wgrad_t<float>(a, splitk, s); }
 
 // Does the split-K weight gradient of this shape take the ring kernel?  256 x 160 tiles, one workgroup per CU: it needs at least a dozen tiles to be
-// worth it (attn.proj, 480 x 480 = 6 tiles, stays on the two-workgroup kernel: 32.8 vs 34.5 us at 16 splits).
+// worth it (attn.proj, 480 x 480 = 6 tiles, stays on the two-workgroup kernel: 32.8 vs 34.5 us at 16 splits alone; inside the step the ring kernel at 8 splits =
+// 48 workgroups measured 225.0 vs 228.5 steps/s, round 3, same box).
 static bool wgrad_ring_shape(Mode m, int I, int J) {
   const int tiles = ((I + 255) / 256) * (J / 160);
   if (m != MODE_BF16 || I < 160 || J % 160 != 0 || I % 8 != 0 || g_kernel == KERNEL_TWO_WG) return false;

@@ -29,6 +29,9 @@
 #pragma once
 #include "v4h_gemm.h"
 
+// cache policy of the saved GELU derivative (buffer instruction aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): non-temporal, see store8_saved (v4h_gemm.h)
+#define V4H_SAVED_AUX 2
+
 
 // Fragment addressing with a minimum of registers.  The images are the dense swizzled ones of v4h_gemm.h; what is new is that a wave keeps only
 // the byte offsets that really differ per lane (2 to 4 integers per operand) and reaches every other fragment through the instruction's
@@ -313,7 +316,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
 #pragma unroll
             for (int r = 0; r < 8; ++r) { v.v[r] = gelu_only<bf16>(v.v[r]); d.v[r] = 0.f; }
           }
-          __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rd, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, 0);  // (inference: zero-sized buffer, dropped)
+          __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rd, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, V4H_SAVED_AUX);  // (inference: zero-sized buffer, dropped)
           __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro2, chunk_off(n, pA2, pB2, a.e.ldo2) * 2u, 0, 0);
         }
       } else {  // EPI_DGELU: out = acc * aux
@@ -324,7 +327,7 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
         for (int h = 0; h < C::NCHUNK; h += 5) {
           u32x4 raw[5];
 #pragma unroll
-          for (int n = 0; n < 5; ++n) raw[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(h + n, xA, xB, a.e.ld_aux) * 2u, 0, 0);
+          for (int n = 0; n < 5; ++n) raw[n] = __builtin_amdgcn_raw_buffer_load_b128(rx, chunk_off(h + n, xA, xB, a.e.ld_aux) * 2u, 0, V4H_SAVED_AUX);
 #pragma unroll
           for (int n = 0; n < 5; ++n) {
             f32x8 v = chunk_val(h + n);
