@@ -1,13 +1,14 @@
 """Copy the summaries of a tools/refresh_profiles.sh run (gpurun_out/refresh_<tag>/) into profiles/ under round-stable names and rebuild the all-workload table.
-usage: python tools/collect_profiles.py <tag> [round prefix, default r02]"""
+usage: python tools/collect_profiles.py <tag> [round prefix, default r03]"""
 import json, os, shutil, sys
 
 tag = sys.argv[1]
-rp = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rp = sys.argv[2] if len(sys.argv) > 2 else "r03"
 R = f"gpurun_out/refresh_{tag}"
 for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"),
                  ("step_pmc_counters.md", f"{rp}_step_pmc_counters.md"), ("step_hbm_traffic.json", "step_hbm_traffic.json"), ("bench_final_bf16.json", f"{rp}_bench_final_bf16.json"),
-                 ("ab_in_context.txt", f"{rp}_ab_in_context_{tag}.txt")):
+                 ("ab_in_context.txt", f"{rp}_ab_in_context_{tag}.txt"), ("ds3_step_serialized.md", f"{rp}_ds3_step_serialized.md"),
+                 ("block_gemm_bench.txt", f"{rp}_block_gemm_bench.txt"), ("attn_bench.txt", f"{rp}_attn_bench.txt")):
     if os.path.exists(f"{R}/{src}"):
         shutil.copy(f"{R}/{src}", f"profiles/{dst}")
 if os.path.exists(f"{R}/gemm2_ablation.txt"):
@@ -17,9 +18,11 @@ if os.path.exists(f"{R}/gemm2_ablation.txt"):
 names = {"ds2": "bench_final_bf16.json", "ds3": "bench_ds3.json", "ds2_d2": "bench_ds2_d2.json", "lemurs": "bench_lemurs.json", "ds1_photons": "bench_ds1_photons.json",
          "ds1_pions": "bench_ds1_pions.json", "calogan": "bench_calogan.json", "calohad": "bench_calohad.json", "ds2 f32 mode": "bench_ds2_f32.json",
          "ds2, collectives forced on (1 rank)": "bench_ds2_forced_collectives.json"}
-out = [f"# bench.py on one MI355X, round 2 final build (tools/refresh_profiles.sh {tag}; bf16 mode unless noted)", "",
+out = [f"# bench.py on one MI355X, final build of the round (tools/refresh_profiles.sh {tag}; bf16 mode unless noted)", "",
        "| workload | per-GPU batch | steps/s | ms/step | TFLOP/s | fraction of the dense MFMA spec peak |", "|---|---|---|---|---|---|"]
 for k, f in names.items():
+    if not os.path.exists(f"{R}/{f}"):
+        continue
     r = json.loads(open(f"{R}/{f}").read().strip().splitlines()[-1])
     out.append(f"| {k} ({r['config']['workload']}) | {r['config']['per_gpu_batch']} | {r['value']} | {r['ms_per_step']} | {r['roofline']['achieved']} | {r['roofline']['frac']} |")
 r = json.loads(open(f"{R}/bench_final_bf16.json").read().strip().splitlines()[-1])
@@ -29,6 +32,6 @@ out += ["", f"Sampling (BASELINE config 5; ds2, batch 256, bf16): RK4 step 0.05 
         f"CPU oracle on the same box ({r['cpu_baseline']['cpu']}): {r['cpu_baseline']['value']} steps/s on {r['cpu_baseline']['cores']} threads; "
         f"{r['cpu_baseline']['one_thread']['value']} steps/s on one thread ({r['cpu_baseline']['one_thread']['sample']}).",
         f"HBM traffic of one update step (PMC, same build): {r['roofline']['traffic']/1e9:.2f} GB.",
-        "Contraction rates inside this run (`gemm_ops`): " + "; ".join(f"{k} {v['us']} us = {v['tflops']} TFLOP/s" for k, v in r["gemm_ops"].items()) + "."]
+        "Contraction rates inside this run (`gemm_ops`): " + "; ".join(f"{k} {v['us']} us = {v['tflops']} TFLOP/s" for k, v in r["gemm_ops"].items() if isinstance(v, dict)) + "." + (" (" + r["gemm_ops"]["_note"] + ")" if "_note" in r["gemm_ops"] else "")]
 open(f"profiles/{rp}_bench_all_workloads.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
