@@ -716,6 +716,9 @@ template <typename T, int DH, int NW> __global__ __launch_bounds__(64 * NW) void
 namespace {
 using v4h_dense::attn_fwd_dense_kernel;
 using v4h_dense::DenseImage;
+using v4h_dense::attn_fwd_long_kernel;
+using v4h_dense::AL_NT;
+using v4h_dense::AL_NW;
 
 template <typename K> int set_lds(K kernel, size_t bytes, const char* name) {
   if (bytes > 48 * 1024) {
@@ -766,6 +769,15 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
                                  : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, v4h_compute_units(), s);
       if (rc) return rc;
       V4H_CHECK_LAUNCH("attn_fwd_dense");
+      return V4H_OK;
+    }
+    if (dense && ntiles >= 24 && ntiles <= AL_NT && (long)H * 80 * 2 * 3 * Tn < 0x7FFFFF00L) {  // 369..480 tokens (ds3): whole-item K / V images in LDS
+      const size_t lds = 2 * (size_t)DenseImage<AL_NT, AL_NW>::BYTES;
+      int rc = set_lds(attn_fwd_long_kernel<2>, lds, "attn_fwd_long");
+      if (rc) return rc;
+      hipLaunchKernelGGL((attn_fwd_long_kernel<2>), dim3(v4h_compute_units()), dim3(64 * AL_NW), lds, s, (const bf16*)qkv, (bf16*)o, lse, Tn, H, B * H,
+                         1.0f / sqrtf((float)DH));
+      V4H_CHECK_LAUNCH("attn_fwd_long");
       return V4H_OK;
     }
     static const bool persist = !(getenv("V4H_ATTN_PERSIST") && getenv("V4H_ATTN_PERSIST")[0] == '0');

@@ -56,13 +56,13 @@ constexpr int AD_DH = 80, AD_ROWB = 160;  // head_dim, bytes per image row (dens
 // Image of NT * 16 rows x 80 bf16 (dense 160-byte rows) filled by buffer_load ... lds: instruction `inst` writes bytes [inst * 1024, + 1024), lane `l` its 16-byte
 // unit u = inst * 64 + l = (row u / 10, chunk u % 10).  The source offset of a unit is fixed for the whole kernel (row * ld_bytes + chunk * 16, relative to the
 // item's q/k/v base in the descriptor); units of rows >= T lie beyond the descriptor's range and read as zero.
-template <int NT> struct DenseImage {
-  static constexpr int ROWS = NT * 16, UNITS = ROWS * 10, NI = (UNITS + 63) / 64, BYTES = NI * 1024, NPW = (NI + NT - 1) / NT;
-  unsigned voff[NPW];  // per DMA instruction of this wave (inst = wave + k * NT): the lane's source byte offset
+template <int NT, int NWV = NT> struct DenseImage {  // NWV: waves that share the DMA instructions
+  static constexpr int ROWS = NT * 16, UNITS = ROWS * 10, NI = (UNITS + 63) / 64, BYTES = NI * 1024, NPW = (NI + NWV - 1) / NWV;
+  unsigned voff[NPW];  // per DMA instruction of this wave (inst = wave + k * NWV): the lane's source byte offset
   V4H_DEV void init(int wave, int lane, int ld_bytes) {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
-      const int u = (wave + k * NT) * 64 + lane;
+      const int u = (wave + k * NWV) * 64 + lane;
       voff[k] = u < UNITS ? (unsigned)((u / 10) * ld_bytes + (u % 10) * 16) : 0x7FFFFF00u;
     }
   }
@@ -71,7 +71,7 @@ template <int NT> struct DenseImage {
   V4H_DEV void stage(__amdgpu_buffer_rsrc_t rsrc, char* img, unsigned add, int wave) const {
 #pragma unroll
     for (int k = 0; k < NPW; ++k) {
-      const int inst = wave + k * NT;
+      const int inst = wave + k * NWV;
       if (inst < NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (V4H_LDS void*)(img + inst * 1024), 16, voff[k] + add, 0, 0, 0);
     }
   }
@@ -236,5 +236,138 @@ template <int NT, int WPE, int NBUF> __global__ __launch_bounds__(64 * NT, WPE) 
   template __global__ void attn_fwd_dense_kernel<NT, WPE, NBUF>(const bf16* __restrict__, bf16* __restrict__, float* __restrict__, int, int, int, float);
 V4H_DENSE_FWD(9, 3, 2) V4H_DENSE_FWD(10, 3, 2)
 #undef V4H_DENSE_FWD
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Sequences of 369 .. 480 tokens (CaloChallenge ds3: T = 450), bf16, head_dim 80.  The K and V images of a WHOLE (batch, head) item fit the CU's LDS
+// (2 x 30 x 16 rows x 160 bytes = 150 KB), so the single-chunk form above carries over: one 8-wave workgroup per CU, images filled by
+// buffer_load ... lds through one descriptor per item, a wave owns 16 query rows at a time and keeps the whole score row (30 tiles) in registers - no
+// online-softmax rescaling, no chunk loop, no second pass over K.  A work unit is HALF of an item's query tiles (QSPLIT = 2): B * H = 384 items on 256
+// CUs are 1.5 rounds, 768 halves are exactly 3, and the two halves of an item sit next to each other on one XCD, so the second fill comes from L2.
+// Replaces attn_fwd_kernel's key chunks of 160 rows staged through registers (99.5 us per call at ds3 B = 64).
+constexpr int AL_NT = 30, AL_NW = 8;
+// Per unit: fill both images (150 KB), wait, two rounds of query tiles per wave.  Measured at ds3 B = 64: 63.8 us per call (390 TFLOP/s).  A pipelined form
+// (V fill under the first score phase, the next unit's K fill under the last P V phase, DMA requests hidden from the compiler in inline assembly because
+// its wait-count pass puts vmcnt(0) in front of every transposed LDS read that follows a visible LDS-DMA) was built, verified and measured at 63.4 us: the
+// unit is bound by LDS reads, not by the fill - every query tile reads both images again, 2.2 MB per unit at 128 bytes per clock = 8 of the unit's 21 us -
+// so the simple form stays.
+template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_fwd_long_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o, float* __restrict__ lse,
+                                                                                           int Tn, int H, int nitems, float scale) {
+  constexpr int NT = AL_NT;
+  using IMG = DenseImage<NT, AL_NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K image | V image]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * AD_DH, ldb = 3 * D * 2;
+  const int Bn = nitems / H;
+  const float c2 = scale * 1.4426950408889634f;
+  const int ntiles = (Tn + 15) >> 4;                      // 24 .. 30 (launcher)
+  const int tph = (ntiles + QSPLIT - 1) / QSPLIT;         // query tiles per unit
+  bool dead[4];                                           // rows >= Tn of the last key tile
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dead[r] = (ntiles - 1) * 16 + 4 * g + r >= Tn;
+  IMG img;
+  img.init(wave, lane, ldb);
+  for (int i = tid * 16; i < 2 * IMG::BYTES; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  const bf16* sK = reinterpret_cast<const bf16*>(smem);
+  const bf16* sV = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
+  Frag<bf16> ones;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) ones.v[r] = (bf16)1.0f;
+  const int ge = g & 1, gh = g >> 1;
+
+  int u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, 0, Bn, H * QSPLIT));
+  for (int n = 0; u >= 0; ++n) {
+    const int it = u / QSPLIT, half = u - it * QSPLIT;
+    const int b = it / H, h = it - b * H;
+    const bf16* ibase = qkv + ((size_t)b * Tn * 3 * D + h * AD_DH);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(ibase), 0, (Tn - 1) * ldb + 4 * D + AD_ROWB, 0x00020000);
+    bf16* obase = o + ((size_t)b * Tn * D + h * AD_DH);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (Tn - 1) * D * 2 + AD_ROWB, 0x00020000);
+    __syncthreads();  // every wave is done with the previous unit's images (first unit: the zero fill is complete)
+    img.stage(rq, smem, 2u * D, wave);
+    img.stage(rq, smem + IMG::BYTES, 4u * D, wave);
+    const int q_lo = half * tph, q_hi = min(ntiles, q_lo + tph);
+    int qt = q_lo + wave;
+    // this wave's 16 query rows (lane side): two K = 32 slabs and the tail of head_dim (lanes g >= 2 load zeros: outside the descriptor)
+    auto q_load = [&](int t, u32x4_& a0, u32x4_& a1, u32x4_& a2) {
+      const unsigned off = (unsigned)((t * 16 + c) * ldb + 16 * g);
+      a0 = __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0);
+      a1 = __builtin_amdgcn_raw_buffer_load_b128(rq, off + 64, 0, 0);
+      a2 = __builtin_amdgcn_raw_buffer_load_b128(rq, g < 2 ? off + 128 : 0x7FFFFF00u, 0, 0);
+    };
+    u32x4_ q0n = {0u, 0u, 0u, 0u}, q1n = q0n, q2n = q0n;
+    if (qt < q_hi) q_load(qt, q0n, q1n, q2n);
+    __syncthreads();  // (vmcnt(0) + barrier) the images have landed for every wave
+    for (; qt < q_hi; qt += AL_NW) {
+      Frag<bf16> xq0, xq1, xq2;
+      xq0.v = __builtin_bit_cast(bf16x8, q0n);
+      xq1.v = __builtin_bit_cast(bf16x8, q1n);
+      xq2.v = __builtin_bit_cast(bf16x8, q2n);
+      if (qt + AL_NW < q_hi) q_load(qt + AL_NW, q0n, q1n, q2n);  // the next round's rows, under this round's products
+      // ---- scores, raw: p[jt][r] = q_c . k_(16 jt + 4 g + r); tiles beyond the sequence are skipped (wave-uniform) and count as -inf
+      f32x4 p[NT];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (jt < 24 || jt < ntiles) {
+          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 0, lane), xq0, a);
+          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 32, lane), xq1, a);
+          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 64, lane), xq2, a);
+        }
+        p[jt] = a;
+      }
+#pragma unroll
+      for (int jt = 23; jt < NT; ++jt) {
+        if (jt == ntiles - 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[jt][r] = dead[r] ? -INFINITY : p[jt][r];
+        } else if (jt >= ntiles) {
+          p[jt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+      }
+      float mx = p[0][0];
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt) {
+        mx = fmaxf(fmaxf(mx, p[jt][0]), p[jt][1]);
+        mx = fmaxf(fmaxf(mx, p[jt][2]), p[jt][3]);
+      }
+      mx = max_xor32(max_xor16(mx));
+      const float m2 = mx * c2;
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[jt][r] = __builtin_amdgcn_exp2f(fmaf(p[jt][r], c2, -m2));
+      // ---- o = P V and the row sum of the bf16-rounded P (sixth output tile against an all-ones operand)
+      f32x4 oacc[6];
+#pragma unroll
+      for (int dt = 0; dt < 6; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NT / 2; ++ks) {
+        if (ks < 12 || 2 * ks < ntiles) {  // (a skipped tile of an odd count has p = 0 and meets zero rows of the V image)
+          const Frag<bf16> wf = acc_pair_frag(p[2 * ks], p[2 * ks + 1]);
+#pragma unroll
+          for (int dt = 0; dt < 5; ++dt) oacc[dt] = mma(frag_kstrided2(sV, AD_DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
+          oacc[5] = mma(ones, wf, oacc[5]);
+        }
+      }
+      const float l = oacc[5][0];
+      const float inv = __builtin_amdgcn_rcpf(l);
+      const unsigned o_off = (unsigned)((qt * 16 + c) * D * 2);
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) oacc[dt] *= inv;  // (before the lane exchange: see the note in the single-chunk kernel)
+#pragma unroll
+      for (int d = 0; d < 4; d += 2)
+        __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(swap_pair(oacc[d], oacc[d + 1])), ro, o_off + (unsigned)(((d + ge) * 16 + 8 * gh) * 2), 0, 0);
+      {
+        const u32x2_ w{pack_bf16(oacc[4][0], oacc[4][1]), pack_bf16(oacc[4][2], oacc[4][3])};
+        __builtin_amdgcn_raw_buffer_store_b64(w, ro, o_off + (unsigned)((64 + 4 * g) * 2), 0, 0);
+      }
+      const int q = qt * 16 + c;
+      if (lse != nullptr && g == 0 && q < Tn) lse[((size_t)b * H + h) * Tn + q] = mx * scale + __logf(l);
+    }
+    u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H * QSPLIT));
+  }
+}
+template __global__ void attn_fwd_long_kernel<2>(const bf16* __restrict__, bf16* __restrict__, float* __restrict__, int, int, int, float);
 
 }  // namespace v4h_dense

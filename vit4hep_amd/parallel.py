@@ -73,10 +73,12 @@ class BucketReducer:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
-        """Make the current stream (or the host, on CPU) wait for every outstanding bucket.  On the GPU the buckets of one communicator complete in
+        """Make the current stream (or the host, on CPU) wait for every outstanding bucket.  Over RCCL the buckets of one communicator complete in
         issue order on one stream, so the current stream waits for the LAST one only: each wait is a barrier packet in the compute queue, and eight of them
-        in a row at the end of the backward cost 2 % of the step (profiles/r03_comm_interference.md)."""
-        for w in (self.pending[-1:] if self.cuda else self.pending):
+        in a row at the end of the backward cost 2 % of the step (profiles/r03_comm_interference.md).  Any other backend (gloo with device tensors stages
+        every bucket through the host on a stream of its own) is waited for bucket by bucket."""
+        last_only = self.cuda and self.pending and dist.get_backend(self.group) == "nccl"
+        for w in (self.pending[-1:] if last_only else self.pending):
             w.wait()
         self.pending = []
 
