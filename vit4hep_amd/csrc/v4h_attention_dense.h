@@ -53,6 +53,22 @@ V4H_DEV Frag<bf16> acc_half_frag(f32x4 a0) {  // the same with a zero second til
 
 constexpr int AD_DH = 80, AD_ROWB = 160;  // head_dim, bytes per image row (dense)
 
+// Fragment reads from a dense image through per-lane base pointers fixed for the whole kernel: the row / column of a tile is then a constant byte offset
+// of the DS instruction (the generic helpers rebuild base + row + lane terms per call, which the compiler hoists out of the unit loop as one address
+// register per tile and then spills).  kc = image + c * 80 + 8 g (k-contiguous reads), ks = image + (4 g + q) * 80 + 4 p (transposed reads).
+V4H_DEV Frag<bf16> lane_kcontig(const bf16* kc, int row0, int k0) {
+  Frag<bf16> f;
+  f.v = *reinterpret_cast<const bf16x8*>(kc + row0 * AD_DH + k0);
+  return f;
+}
+V4H_DEV Frag<bf16> lane_kstrided(const bf16* ks, int row0, int col0) {  // rows row0 + 4 g + 0..3 and row0 + 16 + 4 g + 0..3, columns col0 + c
+  const bf16x4 lo = lds_tr_read(ks + row0 * AD_DH + col0), hi = lds_tr_read(ks + (row0 + 16) * AD_DH + col0);
+  Frag<bf16> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+
+
 // Image of NT * 16 rows x 80 bf16 (dense 160-byte rows) filled by buffer_load ... lds: instruction `inst` writes bytes [inst * 1024, + 1024), lane `l` its 16-byte
 // unit u = inst * 64 + l = (row u / 10, chunk u % 10).  The source offset of a unit is fixed for the whole kernel (row * ld_bytes + chunk * 16, relative to the
 // item's q/k/v base in the descriptor); units of rows >= T lie beyond the descriptor's range and read as zero.
@@ -270,6 +286,8 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_fwd_
   for (int i = tid * 16; i < 2 * IMG::BYTES; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
   const bf16* sK = reinterpret_cast<const bf16*>(smem);
   const bf16* sV = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
+  const bf16* kKc = sK + c * AD_DH + 8 * g;                                     // per-lane bases of the fragment reads (lane_kcontig / lane_kstrided)
+  const bf16* kVs = sV + (4 * g + ((lane >> 2) & 3)) * AD_DH + 4 * (lane & 3);
   Frag<bf16> ones;
 #pragma unroll
   for (int r = 0; r < 8; ++r) ones.v[r] = (bf16)1.0f;
@@ -310,9 +328,9 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_fwd_
       for (int jt = 0; jt < NT; ++jt) {
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
         if (jt < 24 || jt < ntiles) {
-          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 0, lane), xq0, a);
-          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 32, lane), xq1, a);
-          a = mma(frag_kcontig(sK, AD_DH, jt * 16, 64, lane), xq2, a);
+          a = mma(lane_kcontig(kKc, jt * 16, 0), xq0, a);
+          a = mma(lane_kcontig(kKc, jt * 16, 32), xq1, a);
+          a = mma(lane_kcontig(kKc, jt * 16, 64), xq2, a);
         }
         p[jt] = a;
       }
@@ -346,7 +364,7 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_fwd_
         if (ks < 12 || 2 * ks < ntiles) {  // (a skipped tile of an odd count has p = 0 and meets zero rows of the V image)
           const Frag<bf16> wf = acc_pair_frag(p[2 * ks], p[2 * ks + 1]);
 #pragma unroll
-          for (int dt = 0; dt < 5; ++dt) oacc[dt] = mma(frag_kstrided2(sV, AD_DH, 32 * ks, 32 * ks + 16, dt * 16, lane), wf, oacc[dt]);
+          for (int dt = 0; dt < 5; ++dt) oacc[dt] = mma(lane_kstrided(kVs, 32 * ks, dt * 16), wf, oacc[dt]);
           oacc[5] = mma(ones, wf, oacc[5]);
         }
       }
@@ -369,5 +387,231 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_fwd_
   }
 }
 template __global__ void attn_fwd_long_kernel<2>(const bf16* __restrict__, bf16* __restrict__, float* __restrict__, int, int, int, float);
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Backward for the same sequences (369 .. 480 tokens), as two kernels of the same build as attn_fwd_long_kernel (P is recomputed from the saved
+// log-sum-exp, as everywhere in this file's family; no atomics, deterministic):
+//   dq   K and V images of the item in LDS; a wave owns 16 query rows: s = q k^T and dp = dO v^T tile by tile, ds = p (dp - delta) scale packed to bf16
+//        at once (the whole ds row of 480 keys is 60 registers), then dQ = ds K from the K image read k-strided.  Also writes delta = scale sum_d dO O.
+//   dkv  Q and dO images in LDS, log-sum-exp and delta of the item's rows beside them; a wave owns 16 keys and walks the query tiles in pairs (one K = 32
+//        step of the two output products): s^T, dp^T, p^T, ds^T for the pair, dV += p^T dO, dK += ds^T Q - no score row is kept at all.
+// Replace attn_bwd_dq_kernel / attn_bwd_dkv_kernel (key / query chunks of 160 rows staged through registers, 99.5 + 157.6 us per call at ds3 B = 64).
+constexpr int AL_PAD = 64;  // zero bytes behind the last image: the head_dim tail of an image's last row reads 32 bytes past it (times zero - but not NaN)
+V4H_DEV void store_row5(__amdgpu_buffer_rsrc_t r, unsigned row_off, f32x4* t, int g) {  // 5 output tiles of 16 columns -> 80 bf16 of this lane's row
+  const int ge = g & 1, gh = g >> 1;
+  // the lane exchange below is inline assembly: the wait states an MFMA result needs before a vector instruction reads it are inserted only for
+  // instructions the compiler can see, so they are spent here explicitly (tied to the five tiles, so that their MFMAs are issued before)
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]));
+#pragma unroll
+  for (int d = 0; d < 4; d += 2)
+    __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(swap_pair(t[d], t[d + 1])), r, row_off + (unsigned)(((d + ge) * 16 + 8 * gh) * 2), 0, 0);
+  const u32x2_ w{pack_bf16(t[4][0], t[4][1]), pack_bf16(t[4][2], t[4][3])};
+  __builtin_amdgcn_raw_buffer_store_b64(w, r, row_off + (unsigned)((64 + 4 * g) * 2), 0, 0);
+}
+V4H_DEV void load_row3(__amdgpu_buffer_rsrc_t r, unsigned off, int g, Frag<bf16>& a0, Frag<bf16>& a1, Frag<bf16>& a2) {  // a lane-side row: d = 8 g + 0..7, + 32, + 64 (zero from 80)
+  a0.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  a1.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off + 64, 0, 0));
+  a2.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, g < 2 ? off + 128 : 0x7FFFFF00u, 0, 0));
+}
+
+template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_long_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int Tn, int H,
+                                                                                              int nitems, float scale) {
+  constexpr int NT = AL_NT;
+  using IMG = DenseImage<NT, AL_NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [K image | V image | pad]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * AD_DH, ldb = 3 * D * 2, ldo = D * 2;
+  const int Bn = nitems / H;
+  const float c2 = scale * 1.4426950408889634f;
+  const int ntiles = (Tn + 15) >> 4;
+  const int tph = (ntiles + QSPLIT - 1) / QSPLIT;
+  bool dead[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dead[r] = (ntiles - 1) * 16 + 4 * g + r >= Tn;
+  IMG img;
+  img.init(wave, lane, ldb);
+  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  const bf16* sK = reinterpret_cast<const bf16*>(smem);
+  const bf16* sV = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
+  const bf16* kKc = sK + c * AD_DH + 8 * g;
+  const bf16* kVc = sV + c * AD_DH + 8 * g;
+  const bf16* kKs = sK + (4 * g + ((lane >> 2) & 3)) * AD_DH + 4 * (lane & 3);
+
+  int u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, 0, Bn, H * QSPLIT));
+  for (int n = 0; u >= 0; ++n) {
+    const int it = u / QSPLIT, half = u - it * QSPLIT;
+    const int b = it / H, h = it - b * H;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(qkv + ((size_t)b * Tn * 3 * D + h * AD_DH)), 0,
+                                                                         (Tn - 1) * ldb + 4 * D + AD_ROWB, 0x00020000);
+    const size_t orow = (size_t)b * Tn * D + h * AD_DH;
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dout + orow), 0, (Tn - 1) * ldo + AD_ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(o + orow), 0, (Tn - 1) * ldo + AD_ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc(dqkv + ((size_t)b * Tn * 3 * D + h * AD_DH), 0, (Tn - 1) * ldb + AD_ROWB, 0x00020000);
+    __syncthreads();  // every wave is done with the previous unit's images
+    img.stage(rq, smem, 2u * D, wave);
+    img.stage(rq, smem + IMG::BYTES, 4u * D, wave);
+    const int q_hi = min(ntiles, (half + 1) * tph);
+    // Both rounds' rows (q, dO of 16 queries each, lane side), their delta = sum_d dO O and log-sum-exp are fetched here, under the fill of the images:
+    // nothing is loaded inside the product loops.
+    Frag<bf16> rq0[2], rq1[2], rq2[2], rd0[2], rd1[2], rd2[2];
+    float rdelta[2], rlse[2];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int qq = (half * tph + wave + AL_NW * rd) * 16 + c;  // (rows of a tile beyond this unit's range are loaded and not used)
+      load_row3(rq, (unsigned)(qq * ldb + 16 * g), g, rq0[rd], rq1[rd], rq2[rd]);
+      load_row3(rdo, (unsigned)(qq * ldo + 16 * g), g, rd0[rd], rd1[rd], rd2[rd]);
+      Frag<bf16> xo0, xo1, xo2;
+      load_row3(ro, (unsigned)(qq * ldo + 16 * g), g, xo0, xo1, xo2);
+      float dq_ = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        dq_ += (float)xo0.v[jj] * (float)rd0[rd].v[jj] + (float)xo1.v[jj] * (float)rd1[rd].v[jj] + (float)xo2.v[jj] * (float)rd2[rd].v[jj];
+      dq_ += __shfl_xor(dq_, 16, 64);
+      dq_ += __shfl_xor(dq_, 32, 64);
+      rdelta[rd] = dq_;
+      rlse[rd] = qq < Tn ? lse[((size_t)b * H + h) * Tn + qq] * 1.4426950408889634f : 0.f;
+    }
+    __syncthreads();  // the images have landed for every wave
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int qt = half * tph + wave + AL_NW * rd;
+      if (qt >= q_hi) break;  // wave-uniform
+      const int q = qt * 16 + c;
+      const Frag<bf16> xq0 = rq0[rd], xq1 = rq1[rd], xq2 = rq2[rd], xd0 = rd0[rd], xd1 = rd1[rd], xd2 = rd2[rd];
+      const float lse2 = rlse[rd], delta_q = rdelta[rd];
+      const float delta_s = delta_q * scale;
+      if (g == 0 && q < Tn) delta[((size_t)b * H + h) * Tn + q] = delta_s;
+      // key tiles in pairs (one K = 32 step of the dQ product): s, dp, p, ds of the pair, then dQ += ds K at once - no score row is kept.  Keys beyond the
+      // sequence need no mask here: their ds is finite and meets zero rows of the K image.
+      f32x4 dq[5];
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; 2 * ks < ntiles; ++ks) {
+        unsigned dw[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j0 = (2 * ks + e) * 16;
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+          a = mma(lane_kcontig(kKc, j0, 0), xq0, a);
+          a = mma(lane_kcontig(kKc, j0, 32), xq1, a);
+          a = mma(lane_kcontig(kKc, j0, 64), xq2, a);
+          d = mma(lane_kcontig(kVc, j0, 0), xd0, d);
+          d = mma(lane_kcontig(kVc, j0, 32), xd1, d);
+          d = mma(lane_kcontig(kVc, j0, 64), xd2, d);
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(a[r], c2, -lse2)) * fmaf(d[r], scale, -delta_s);
+          dw[2 * e] = pack_bf16(ds[0], ds[1]);
+          dw[2 * e + 1] = pack_bf16(ds[2], ds[3]);
+        }
+        Frag<bf16> wf;
+        wf.v = __builtin_bit_cast(bf16x8, u32x4_{dw[0], dw[1], dw[2], dw[3]});
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) dq[dt] = mma(lane_kstrided(kKs, 32 * ks, dt * 16), wf, dq[dt]);
+      }
+      store_row5(rdq, (unsigned)(q * ldb), dq, g);
+    }
+    u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H * QSPLIT));
+  }
+}
+
+template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_long_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                                               bf16* __restrict__ dqkv, int Tn, int H, int nitems, float scale) {
+  constexpr int NT = AL_NT;
+  using IMG = DenseImage<NT, AL_NW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [Q image | dO image | pad | lse (log-2 units) | delta * scale]
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = H * AD_DH, ldb = 3 * D * 2, ldo = D * 2;
+  const int Bn = nitems / H;
+  const float c2 = scale * 1.4426950408889634f;
+  const int ntiles = (Tn + 15) >> 4;
+  const int tph = (ntiles + QSPLIT - 1) / QSPLIT;
+  IMG imq, imd;
+  imq.init(wave, lane, ldb);
+  imd.init(wave, lane, ldo);
+  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  const bf16* sQ = reinterpret_cast<const bf16*>(smem);
+  const bf16* sDO = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
+  float* sLse = reinterpret_cast<float*>(smem + 2 * IMG::BYTES + AL_PAD);
+  float* sDelta = sLse + NT * 16;
+  const bf16* kQc = sQ + c * AD_DH + 8 * g;
+  const bf16* kDc = sDO + c * AD_DH + 8 * g;
+  const bf16* kQs = sQ + (4 * g + ((lane >> 2) & 3)) * AD_DH + 4 * (lane & 3);
+  const bf16* kDs = sDO + (4 * g + ((lane >> 2) & 3)) * AD_DH + 4 * (lane & 3);
+
+  int u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, 0, Bn, H * QSPLIT));
+  for (int n = 0; u >= 0; ++n) {
+    const int it = u / QSPLIT, half = u - it * QSPLIT;
+    const int b = it / H, h = it - b * H;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(qkv + ((size_t)b * Tn * 3 * D + h * AD_DH)), 0,
+                                                                         (Tn - 1) * ldb + 4 * D + AD_ROWB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(dout + ((size_t)b * Tn * D + h * AD_DH)), 0, (Tn - 1) * ldo + AD_ROWB,
+                                                                          0x00020000);
+    const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(dqkv + ((size_t)b * Tn * 3 * D + h * AD_DH), 0, (Tn - 1) * ldb + 4 * D + AD_ROWB, 0x00020000);
+    __syncthreads();  // every wave is done with the previous unit's images and rows
+    imq.stage(rq, smem, 0u, wave);
+    imd.stage(rdo, smem + IMG::BYTES, 0u, wave);
+    for (int r = tid; r < NT * 16; r += 64 * AL_NW) {  // a query row beyond the sequence gets p = exp2(s - huge) = 0
+      sLse[r] = r < Tn ? lse[((size_t)b * H + h) * Tn + r] * 1.4426950408889634f : 1e30f;
+      sDelta[r] = r < Tn ? delta[((size_t)b * H + h) * Tn + r] : 0.f;
+    }
+    const int k_hi = min(ntiles, (half + 1) * tph);
+    __syncthreads();  // images and rows have landed for every wave
+    for (int kt = half * tph + wave; kt < k_hi; kt += AL_NW) {
+      const int key = kt * 16 + c;
+      Frag<bf16> xk0, xk1, xk2, xv0, xv1, xv2;  // this wave's 16 keys, lane side (fetching both rounds' rows under the fill measured slower: 105.8 vs 89.7 us)
+      load_row3(rq, (unsigned)(key * ldb + 2 * D + 16 * g), g, xk0, xk1, xk2);
+      load_row3(rq, (unsigned)(key * ldb + 4 * D + 16 * g), g, xv0, xv1, xv2);
+      f32x4 dk[5], dv[5];
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; 2 * ks < ntiles; ++ks) {
+        Frag<bf16> pf, df;
+        unsigned pw[4], dw[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int i0 = (2 * ks + e) * 16;  // (an odd count's last pair has a second tile of zero rows: lse = huge there, p = 0)
+          f32x4 a = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+          a = mma(lane_kcontig(kQc, i0, 0), xk0, a);
+          a = mma(lane_kcontig(kQc, i0, 32), xk1, a);
+          a = mma(lane_kcontig(kQc, i0, 64), xk2, a);
+          d = mma(lane_kcontig(kDc, i0, 0), xv0, d);
+          d = mma(lane_kcontig(kDc, i0, 32), xv1, d);
+          d = mma(lane_kcontig(kDc, i0, 64), xv2, d);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(sLse + i0 + 4 * g), e4 = *reinterpret_cast<const f32x4*>(sDelta + i0 + 4 * g);
+          float pr[4], ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pr[r] = __builtin_amdgcn_exp2f(fmaf(a[r], c2, -l4[r]));
+            ds[r] = pr[r] * fmaf(d[r], scale, -e4[r]);
+          }
+          pw[2 * e] = pack_bf16(pr[0], pr[1]); pw[2 * e + 1] = pack_bf16(pr[2], pr[3]);
+          dw[2 * e] = pack_bf16(ds[0], ds[1]); dw[2 * e + 1] = pack_bf16(ds[2], ds[3]);
+        }
+        pf.v = __builtin_bit_cast(bf16x8, u32x4_{pw[0], pw[1], pw[2], pw[3]});
+        df.v = __builtin_bit_cast(bf16x8, u32x4_{dw[0], dw[1], dw[2], dw[3]});
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) {
+          dv[dt] = mma(lane_kstrided(kDs, 32 * ks, dt * 16), pf, dv[dt]);
+          dk[dt] = mma(lane_kstrided(kQs, 32 * ks, dt * 16), df, dk[dt]);
+        }
+      }
+      store_row5(rdx, (unsigned)(key * ldb + 2 * D), dk, g);
+      store_row5(rdx, (unsigned)(key * ldb + 4 * D), dv, g);
+    }
+    u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H * QSPLIT));
+  }
+}
+template __global__ void attn_bwd_long_dq_kernel<2>(const bf16* __restrict__, const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__,
+                                                    float* __restrict__, bf16* __restrict__, int, int, int, float);
+template __global__ void attn_bwd_long_dkv_kernel<2>(const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__, const float* __restrict__,
+                                                     bf16* __restrict__, int, int, int, float);
 
 }  // namespace v4h_dense
