@@ -5,7 +5,7 @@ import json, os, shutil, sys
 tag = sys.argv[1]
 rp = sys.argv[2] if len(sys.argv) > 2 else "r03"
 R = f"gpurun_out/refresh_{tag}"
-for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"),
+for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"), ("step_timeline.txt", f"{rp}_step_timeline.txt"),
                  ("step_pmc_counters.md", f"{rp}_step_pmc_counters.md"), ("step_hbm_traffic.json", "step_hbm_traffic.json"), ("bench_final_bf16.json", f"{rp}_bench_final_bf16.json"),
                  ("ab_in_context.txt", f"{rp}_ab_in_context_{tag}.txt"), ("ds3_step_serialized.md", f"{rp}_ds3_step_serialized.md"),
                  ("block_gemm_bench.txt", f"{rp}_block_gemm_bench.txt"), ("attn_bench.txt", f"{rp}_attn_bench.txt")):

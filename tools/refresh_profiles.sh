@@ -23,6 +23,7 @@ echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ovl -o p -- python3 bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/prof_ovl.log 2>&1
 python3 tools/profile_summary.py $out/prof_ovl 17 $out/step_overlapped.md > /dev/null
 python3 tools/gap_analysis.py $out/prof_ovl 17 > $out/step_gaps.txt
+python3 tools/timeline.py $out/prof_ovl 3 > $out/step_timeline.txt
 echo "overlapped profile done"
 V4H_WGRAD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ser -o p -- python3 bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/prof_ser.log 2>&1
 python3 tools/profile_summary.py $out/prof_ser 17 $out/step_serialized.md > /dev/null
