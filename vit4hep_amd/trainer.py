@@ -88,7 +88,7 @@ class CFMTrainer:
             self.stage_slices.append(bounds(blk0 + 10 * i, blk0 + 10 * (i + 1)))
         self.stage_slices.append(bounds(0, blk0))
         self.reducer = BucketReducer(self.flat_g, self.group)
-        self.comm_reserve_cus = int(os.environ.get("V4H_COMM_RESERVE_CUS", "16"))  # multiple of 8 in [0, 64]
+        self.comm_reserve_cus = int(os.environ.get("V4H_COMM_RESERVE_CUS", "0"))  # multiple of 8 in [0, 64]
         self.stage_events = None
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
@@ -138,9 +138,9 @@ class CFMTrainer:
             # one call; the library records an event when a stage's gradient slice is final and the bucket is reduced behind it
             if self.stage_events is None:
                 self.stage_events = self.reducer.make_stage_events(len(self.stage_slices))
-            # While buckets are in flight the persistent kernels leave a few CUs to the collective's workgroups (read at enqueue time, so it brackets
-            # exactly this pass; results do not depend on it).  16 measured +0.8 % against 0 beside a 16-workgroup ring, neutral beside 8
-            # (profiles/r03_comm_interference.md).
+            # While buckets are in flight the persistent kernels can leave CUs to the collective's workgroups (read at enqueue time, so it brackets
+            # exactly this pass; results do not depend on it).  Rehearsed on one GPU it is neutral (-0.9 ... +1.0 % over two runs of the table in
+            # profiles/r03_comm_interference.md), so the default is 0; the switch is for runs beside the real RCCL kernels.
             _lib.check(lib.v4h_reserve_compute_units(self.comm_reserve_cus), "v4h_reserve_compute_units")
             try:
                 run_backward_events(self.net, self.p_views, self.g_views, dv, ws, self.stage_events)
