@@ -121,6 +121,30 @@ def test_single_chunk_attention_with_several_items_per_workgroup(B, T):
     assert float((o.float().reshape(B, T, H, dh) - want).abs().max()) < 4e-3
 
 
+@pytest.mark.parametrize("B,T", [(128, 135), (40, 160), (48, 150), (9, 129), (44, 450), (43, 470), (45, 369)])
+def test_attention_backward_with_several_items_per_workgroup(B, T):
+    """The persistent backward kernels - single-chunk (T = 129 .. 160) and whole-item images (T = 369 .. 480: attn_bwd_long_dq / _dkv of round 3, half
+    an item per unit) - where a workgroup walks several items / units: dq, dk, dv of every (batch, head) item against
+    torch autograd in f64 on the same bf16 inputs, per item (a stale image, a late DMA or a result stored for the wrong item shows as whole items wrong),
+    and rows beyond the sequence untouched."""
+    H, dh = 6, 80
+    gen = torch.Generator(device=U.DEV).manual_seed(B * 1000 + T)
+    qkv = (torch.randn((B * T, 3 * H * dh), generator=gen, device=U.DEV) * 0.7).to(torch.bfloat16)
+    do = torch.randn((B * T, H * dh), generator=gen, device=U.DEV).to(torch.bfloat16)
+    o, lse = U.attention_fwd("bf16", qkv, B, T, H, dh)
+    q64 = qkv.double().requires_grad_(True)
+    ref = U.ref_attention(q64, B, T, H, dh)
+    assert U.rel_err(o, ref) < 1.5e-2
+    ref.backward(do.double())
+    dqkv = U.attention_bwd("bf16", qkv, o, do, lse, B, T, H, dh)
+    assert bool(torch.isfinite(dqkv.float()).all())
+    err = (dqkv.double() - q64.grad).reshape(B, T, 3, H, dh)
+    scale = q64.grad.abs().reshape(B, T, 3, H, dh).amax(dim=(1, 4), keepdim=True)  # per (sample, q/k/v, head)
+    worst = (err.abs() / scale).amax(dim=(1, 4))
+    assert float(worst.max()) < 4e-2, (int((worst > 4e-2).sum()), "of", worst.numel(), "(item, tensor) slices wrong")
+    assert U.rel_err(dqkv, q64.grad) < 3e-2
+
+
 def test_reserving_compute_units_changes_no_result():
     """v4h_reserve_compute_units(n) shrinks the persistent grids (contractions on both kernels, single-chunk attention forward and backward) to 256 - n
     workgroups; the tile walk redistributes and no value may change.  Loss and every gradient of an update step at n = 0, 0, 16, 64."""

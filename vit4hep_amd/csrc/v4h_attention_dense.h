@@ -614,4 +614,9 @@ template __global__ void attn_bwd_long_dq_kernel<2>(const bf16* __restrict__, co
 template __global__ void attn_bwd_long_dkv_kernel<2>(const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__, const float* __restrict__,
                                                      bf16* __restrict__, int, int, int, float);
 
+// (A single-chunk backward built from these inner loops - the schedule of attn_bwd_fused_kernel with immediate-offset fragment reads, zero rows instead of
+// per-element masks, pair loops and query rows fetched a phase ahead: 168 VGPRs, every test green - measured 58.7 us per call against the fused kernel's
+// 54.3-55.6 on the same box and was removed: at 2-3 waves per SIMD that kernel waits on its own dependency chains and barriers, not on its vector
+// instruction count.  profiles/r03_attn_counters.md.)
+
 }  // namespace v4h_dense
