@@ -123,7 +123,7 @@ def test_single_chunk_attention_with_several_items_per_workgroup(B, T):
 
 @pytest.mark.parametrize("B,T", [(128, 135), (40, 160), (48, 150), (9, 129), (44, 450), (43, 470), (45, 369)])
 def test_attention_backward_with_several_items_per_workgroup(B, T):
-    """The persistent backward kernels - single-chunk (T = 129 .. 160) and whole-item images (T = 369 .. 480: attn_bwd_long_dq / _dkv of round 3, half
+    """The persistent backward kernels - single-chunk (T = 129 .. 160) and whole-item images (T = 369 .. 480: attn_bwd_dq_img / attn_bwd_dkv_img of round 3, half
     an item per unit) - where a workgroup walks several items / units: dq, dk, dv of every (batch, head) item against
     torch autograd in f64 on the same bf16 inputs, per item (a stale image, a late DMA or a result stored for the wrong item shows as whole items wrong),
     and rows beyond the sequence untouched."""

@@ -717,8 +717,8 @@ namespace {
 using v4h_dense::attn_fwd_dense_kernel;
 using v4h_dense::DenseImage;
 using v4h_dense::attn_fwd_long_kernel;
-using v4h_dense::attn_bwd_long_dq_kernel;
-using v4h_dense::attn_bwd_long_dkv_kernel;
+using v4h_dense::attn_bwd_dq_img_kernel;
+using v4h_dense::attn_bwd_dkv_img_kernel;
 using v4h_dense::AL_PAD;
 using v4h_dense::AL_NT;
 using v4h_dense::AL_NW;
@@ -841,15 +841,15 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
     if (dense && ntiles >= 24 && ntiles <= AL_NT && (long)H * 80 * 2 * 3 * Tn < 0x7FFFFF00L) {  // 369..480 tokens (ds3): whole-item images in LDS
       const size_t img2 = 2 * (size_t)DenseImage<AL_NT, AL_NW>::BYTES;
       const float scale = 1.0f / sqrtf((float)DH);
-      int rc = set_lds(attn_bwd_long_dq_kernel<2>, img2 + AL_PAD, "attn_bwd_long_dq");
+      int rc = set_lds(attn_bwd_dq_img_kernel<AL_NT, AL_NW, 2, 1>, img2 + AL_PAD, "attn_bwd_long_dq");
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_bwd_long_dq_kernel<2>), dim3(v4h_compute_units()), dim3(64 * AL_NW), img2 + AL_PAD, s, (const bf16*)qkv, (const bf16*)o,
+      hipLaunchKernelGGL((attn_bwd_dq_img_kernel<AL_NT, AL_NW, 2, 1>), dim3(v4h_compute_units()), dim3(64 * AL_NW), img2 + AL_PAD, s, (const bf16*)qkv, (const bf16*)o,
                          (const bf16*)dout, lse, delta, (bf16*)dqkv, Tn, H, B * H, scale);
       V4H_CHECK_LAUNCH("attn_bwd_long_dq");
       const size_t lds2 = img2 + AL_PAD + 2 * AL_NT * 16 * sizeof(float);
-      rc = set_lds(attn_bwd_long_dkv_kernel<2>, lds2, "attn_bwd_long_dkv");
+      rc = set_lds(attn_bwd_dkv_img_kernel<AL_NT, AL_NW, 2, 1>, lds2, "attn_bwd_long_dkv");
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_bwd_long_dkv_kernel<2>), dim3(v4h_compute_units()), dim3(64 * AL_NW), lds2, s, (const bf16*)qkv, (const bf16*)dout, lse,
+      hipLaunchKernelGGL((attn_bwd_dkv_img_kernel<AL_NT, AL_NW, 2, 1>), dim3(v4h_compute_units()), dim3(64 * AL_NW), lds2, s, (const bf16*)qkv, (const bf16*)dout, lse,
                          (const float*)delta, (bf16*)dqkv, Tn, H, B * H, scale);
       V4H_CHECK_LAUNCH("attn_bwd_long_dkv");
       return V4H_OK;

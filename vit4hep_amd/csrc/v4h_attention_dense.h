@@ -414,12 +414,12 @@ V4H_DEV void load_row3(__amdgpu_buffer_rsrc_t r, unsigned off, int g, Frag<bf16>
   a2.v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, g < 2 ? off + 128 : 0x7FFFFF00u, 0, 0));
 }
 
-template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_long_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+template <int NT, int NW, int QSPLIT, int MINB> __global__ __launch_bounds__(64 * NW, MINB) void attn_bwd_dq_img_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                                                               float* __restrict__ delta, bf16* __restrict__ dqkv, int Tn, int H,
                                                                                               int nitems, float scale) {
-  constexpr int NT = AL_NT;
-  using IMG = DenseImage<NT, AL_NW>;
+  constexpr int NRD = (NT / QSPLIT + NW - 1) / NW;  // rounds of tiles per wave and unit
+  using IMG = DenseImage<NT, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [K image | V image | pad]
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,7 +433,7 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
   for (int r = 0; r < 4; ++r) dead[r] = (ntiles - 1) * 16 + 4 * g + r >= Tn;
   IMG img;
   img.init(wave, lane, ldb);
-  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
   const bf16* sK = reinterpret_cast<const bf16*>(smem);
   const bf16* sV = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
   const bf16* kKc = sK + c * AD_DH + 8 * g;
@@ -456,11 +456,11 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
     const int q_hi = min(ntiles, (half + 1) * tph);
     // Both rounds' rows (q, dO of 16 queries each, lane side), their delta = sum_d dO O and log-sum-exp are fetched here, under the fill of the images:
     // nothing is loaded inside the product loops.
-    Frag<bf16> rq0[2], rq1[2], rq2[2], rd0[2], rd1[2], rd2[2];
-    float rdelta[2], rlse[2];
+    Frag<bf16> rq0[NRD], rq1[NRD], rq2[NRD], rd0[NRD], rd1[NRD], rd2[NRD];
+    float rdelta[NRD], rlse[NRD];
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int qq = (half * tph + wave + AL_NW * rd) * 16 + c;  // (rows of a tile beyond this unit's range are loaded and not used)
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int qq = (half * tph + wave + NW * rd) * 16 + c;  // (rows of a tile beyond this unit's range are loaded and not used)
       load_row3(rq, (unsigned)(qq * ldb + 16 * g), g, rq0[rd], rq1[rd], rq2[rd]);
       load_row3(rdo, (unsigned)(qq * ldo + 16 * g), g, rd0[rd], rd1[rd], rd2[rd]);
       Frag<bf16> xo0, xo1, xo2;
@@ -476,8 +476,8 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
     }
     __syncthreads();  // the images have landed for every wave
 #pragma unroll
-    for (int rd = 0; rd < 2; ++rd) {
-      const int qt = half * tph + wave + AL_NW * rd;
+    for (int rd = 0; rd < NRD; ++rd) {
+      const int qt = half * tph + wave + NW * rd;
       if (qt >= q_hi) break;  // wave-uniform
       const int q = qt * 16 + c;
       const Frag<bf16> xq0 = rq0[rd], xq1 = rq1[rd], xq2 = rq2[rd], xd0 = rd0[rd], xd1 = rd1[rd], xd2 = rd2[rd];
@@ -519,11 +519,11 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
   }
 }
 
-template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_long_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+template <int NT, int NW, int QSPLIT, int MINB> __global__ __launch_bounds__(64 * NW, MINB) void attn_bwd_dkv_img_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                                                bf16* __restrict__ dqkv, int Tn, int H, int nitems, float scale) {
-  constexpr int NT = AL_NT;
-  using IMG = DenseImage<NT, AL_NW>;
+  constexpr int NRD = (NT / QSPLIT + NW - 1) / NW;  // rounds of tiles per wave and unit
+  using IMG = DenseImage<NT, NW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [Q image | dO image | pad | lse (log-2 units) | delta * scale]
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -535,7 +535,7 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
   IMG imq, imd;
   imq.init(wave, lane, ldb);
   imd.init(wave, lane, ldo);
-  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * AL_NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
+  for (int i = tid * 16; i < 2 * IMG::BYTES + AL_PAD; i += 64 * NW * 16) *reinterpret_cast<u32x4_*>(smem + i) = u32x4_{0u, 0u, 0u, 0u};
   const bf16* sQ = reinterpret_cast<const bf16*>(smem);
   const bf16* sDO = reinterpret_cast<const bf16*>(smem + IMG::BYTES);
   float* sLse = reinterpret_cast<float*>(smem + 2 * IMG::BYTES + AL_PAD);
@@ -557,13 +557,13 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
     __syncthreads();  // every wave is done with the previous unit's images and rows
     imq.stage(rq, smem, 0u, wave);
     imd.stage(rdo, smem + IMG::BYTES, 0u, wave);
-    for (int r = tid; r < NT * 16; r += 64 * AL_NW) {  // a query row beyond the sequence gets p = exp2(s - huge) = 0
+    for (int r = tid; r < NT * 16; r += 64 * NW) {  // a query row beyond the sequence gets p = exp2(s - huge) = 0
       sLse[r] = r < Tn ? lse[((size_t)b * H + h) * Tn + r] * 1.4426950408889634f : 1e30f;
       sDelta[r] = r < Tn ? delta[((size_t)b * H + h) * Tn + r] : 0.f;
     }
     const int k_hi = min(ntiles, (half + 1) * tph);
     __syncthreads();  // images and rows have landed for every wave
-    for (int kt = half * tph + wave; kt < k_hi; kt += AL_NW) {
+    for (int kt = half * tph + wave; kt < k_hi; kt += NW) {
       const int key = kt * 16 + c;
       Frag<bf16> xk0, xk1, xk2, xv0, xv1, xv2;  // this wave's 16 keys, lane side (fetching both rounds' rows under the fill measured slower: 105.8 vs 89.7 us)
       load_row3(rq, (unsigned)(key * ldb + 2 * D + 16 * g), g, xk0, xk1, xk2);
@@ -609,10 +609,15 @@ template <int QSPLIT> __global__ __launch_bounds__(64 * AL_NW, 1) void attn_bwd_
     u = __builtin_amdgcn_readfirstlane(attn_item(blockIdx.x, gridDim.x, n + 1, Bn, H * QSPLIT));
   }
 }
-template __global__ void attn_bwd_long_dq_kernel<2>(const bf16* __restrict__, const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__,
-                                                    float* __restrict__, bf16* __restrict__, int, int, int, float);
-template __global__ void attn_bwd_long_dkv_kernel<2>(const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__, const float* __restrict__,
-                                                     bf16* __restrict__, int, int, int, float);
+#define V4H_BWD_IMG(NT, NW, QS, MB)                                                                                                                       \
+  template __global__ void attn_bwd_dq_img_kernel<NT, NW, QS, MB>(const bf16* __restrict__, const bf16* __restrict__, const bf16* __restrict__,          \
+                                                                  const float* __restrict__, float* __restrict__, bf16* __restrict__, int, int, int, float); \
+  template __global__ void attn_bwd_dkv_img_kernel<NT, NW, QS, MB>(const bf16* __restrict__, const bf16* __restrict__, const float* __restrict__,         \
+                                                                   const float* __restrict__, bf16* __restrict__, int, int, int, float);
+V4H_BWD_IMG(AL_NT, AL_NW, 2, 1)  // 369 .. 480 tokens: half an item per unit, one workgroup per CU
+// (NT = 10, NW = 10, an item per unit, two workgroups per CU was measured for 129 .. 160 tokens against attn_bwd_fused_kernel: 37.1 + 32.2 us per call
+//  against 55 for the fused kernel - every operand read twice, two fills per item - and is not instantiated)
+#undef V4H_BWD_IMG
 
 // (A single-chunk backward built from these inner loops - the schedule of attn_bwd_fused_kernel with immediate-offset fragment reads, zero rows instead of
 // per-element masks, pair loops and query rows fetched a phase ahead: 168 VGPRs, every test green - measured 58.7 us per call against the fused kernel's
