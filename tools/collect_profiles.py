@@ -11,6 +11,13 @@ for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), 
                  ("block_gemm_bench.txt", f"{rp}_block_gemm_bench.txt"), ("attn_bench.txt", f"{rp}_attn_bench.txt")):
     if os.path.exists(f"{R}/{src}"):
         shutil.copy(f"{R}/{src}", f"profiles/{dst}")
+if os.path.exists(f"{R}/step_pmc_counters.md") and os.path.exists("tools/pmc_counters_header.md"):  # the audit's reading in front of the raw tables
+    open(f"profiles/{rp}_step_pmc_counters.md", "w").write(open("tools/pmc_counters_header.md").read() + "```\n" + open(f"{R}/step_pmc_counters.md").read() + "```\n")
+if os.path.exists(f"{R}/ab_in_context.txt"):
+    open(f"profiles/{rp}_ab_in_context_{tag}.txt", "w").write(
+        "# In-context A/B of the switches the library keeps (tools/refresh_profiles.sh, part 3): two interleaved rounds on one box, each line one full `bench.py` run\n"
+        "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default (automatic choice); 0 / 8 = two-workgroup / ring kernel everywhere; V4H_GEMM2_PP = which\n"
+        "# contraction classes take the ring kernel (default 53); the rest switch one round-3 / round-2 lever off.\n" + open(f"{R}/ab_in_context.txt").read())
 if os.path.exists(f"{R}/gemm2_ablation.txt"):
     hdr = open(f"profiles/{rp}_gemm2_ablation.txt").read().split("\n\n")[0] + "\n\n" if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""
     body = "\n".join(l for l in open(f"{R}/gemm2_ablation.txt").read().splitlines() if "amdgpu.ids" not in l)
