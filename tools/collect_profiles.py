@@ -19,7 +19,8 @@ if os.path.exists(f"{R}/ab_in_context.txt"):
         "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default (automatic choice); 0 / 8 = two-workgroup / ring kernel everywhere; V4H_GEMM2_PP = which\n"
         "# contraction classes take the ring kernel (default 53); the rest switch one round-3 / round-2 lever off.\n" + open(f"{R}/ab_in_context.txt").read())
 if os.path.exists(f"{R}/gemm2_ablation.txt"):
-    hdr = open(f"profiles/{rp}_gemm2_ablation.txt").read().split("\n\n")[0] + "\n\n" if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""
+    old = open(f"profiles/{rp}_gemm2_ablation.txt").read() if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""
+    hdr = old.split("\n\n")[0] + "\n\n" if old.startswith("#") else ""  # (keep a hand-written header, never an old body)
     body = "\n".join(l for l in open(f"{R}/gemm2_ablation.txt").read().splitlines() if "amdgpu.ids" not in l)
     open(f"profiles/{rp}_gemm2_ablation.txt", "w").write(hdr + body + "\n")
 names = {"ds2": "bench_final_bf16.json", "ds3": "bench_ds3.json", "ds2_d2": "bench_ds2_d2.json", "lemurs": "bench_lemurs.json", "ds1_photons": "bench_ds1_photons.json",
