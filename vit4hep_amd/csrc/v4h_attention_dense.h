@@ -13,8 +13,9 @@
 //     scheduled the pair back to back - found with tools/experiments/attn_debug2.py - so no K = 16 instruction is used.)
 //   * addresses everything per item through ONE buffer descriptor built from scalars (item base in SGPRs, per-lane offsets fixed for the whole kernel): no
 //     per-item 64-bit vector address arithmetic, rows >= T are dropped / zero-filled by the descriptor's bounds check instead of by predicates;
-//   * holds ONE pair of K / V images per workgroup (2 x 23 KB for 9 tiles) so that TWO workgroups share a CU: 18 waves (4-5 per SIMD instead of 3-2-2-2)
-//     - the DMA wait and the barrier of one workgroup are the other's compute time, and the SIMD imbalance of nine waves on four SIMDs averages out.
+//   * comes in two forms of the same body: NBUF = 2 (the product form: one workgroup per CU, the next item's images and query rows are requested before the
+//     current item is computed) and NBUF = 1 (one pair of images per workgroup, 2 x 23 KB for 9 tiles, so that two or three workgroups share a CU and one's
+//     DMA wait is another's compute time: measured equal or slower, not instantiated).
 #pragma once
 
 namespace v4h_dense {  // (a named namespace: the host stubs of two of these kernel instantiations were not emitted from an anonymous one)
