@@ -5,7 +5,8 @@
     reaches them (B % 32 == 0) against the oracle's autograd;
   * the fused GELU / DGELU operator entry points (timm Mlp, nn/vit.py:312-322) on both product kernels;
   * the instruction-lean single-chunk attention forward (v4h_attention_dense.h, nn/vit.py:425-451) where a persistent workgroup walks several
-    (batch, head) items - the case a two-sample test never reaches - for both tile counts (T = 135: 9 tiles, T = 160 / 150: 10 tiles).
+    (batch, head) items - the case a two-sample test never reaches - for every tile count it is built for (6 .. 10 tiles: T = 81 .. 160; ds1 photons 88,
+    ds1 pions 125, ds2 / LEMURS 135).
 """
 
 import numpy as np
@@ -93,7 +94,7 @@ def test_gelu_and_dgelu_operators(kernel):
         lib.v4h_select_contraction_kernel(_lib.KERNEL_AUTO)
 
 
-@pytest.mark.parametrize("B,T", [(128, 135), (40, 160), (48, 150), (9, 129)])
+@pytest.mark.parametrize("B,T", [(128, 135), (40, 160), (48, 150), (9, 129), (64, 88), (70, 125), (50, 100), (90, 81)])
 def test_single_chunk_attention_with_several_items_per_workgroup(B, T):
     """256 persistent workgroups, B * 6 (batch, head) items: up to three items per workgroup through the double-buffered images (the second and third
     items are where a stale image, a late DMA or a mis-scheduled MFMA pair would show), rows >= T of the last tile masked / dropped, both tile counts."""

@@ -764,12 +764,16 @@ template <typename T> int attn_fwd_t(const void* qkv, void* o, float* lse, int B
   const int ntiles = (Tn + 15) / 16;
   if constexpr (sizeof(T) == 2) {
     static const int dense = getenv("V4H_ATTN_DENSE") ? atoi(getenv("V4H_ATTN_DENSE")) : 1;  // A/B hook: 0 = round 2's persistent kernel
-    if (dense && Tn <= KC && ntiles >= 9 && (long)H * 80 * 2 * 3 * Tn < 0x7FFFFF00L) {  // 129..160 tokens: the instruction-lean, descriptor-addressed form
+    if (dense && Tn <= KC && ntiles >= 6 && (long)H * 80 * 2 * 3 * Tn < 0x7FFFFF00L) {  // 81..160 tokens: the instruction-lean, descriptor-addressed form
       // (its key mask covers the LAST tile only, so the tile count must be ceil(T / 16); shorter sequences keep the kernels below)
       const int nitems = B * H;
       const float scale = 1.0f / sqrtf((float)DH);
-      const int rc = ntiles <= 9 ? attn_fwd_dense_launch<9, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, v4h_compute_units(), s)
-                                 : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, v4h_compute_units(), s);
+      const int cus = v4h_compute_units();
+      const int rc = ntiles == 6   ? attn_fwd_dense_launch<6, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, cus, s)
+                     : ntiles == 7 ? attn_fwd_dense_launch<7, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, cus, s)
+                     : ntiles == 8 ? attn_fwd_dense_launch<8, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, cus, s)
+                     : ntiles == 9 ? attn_fwd_dense_launch<9, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, cus, s)
+                                   : attn_fwd_dense_launch<10, 3, 2>(qkv, o, lse, Tn, H, nitems, scale, cus, s);
       if (rc) return rc;
       V4H_CHECK_LAUNCH("attn_fwd_dense");
       return V4H_OK;

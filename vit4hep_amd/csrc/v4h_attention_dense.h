@@ -1,4 +1,5 @@
-// Single-chunk attention (sequences of at most 160 tokens: ds2 / LEMURS T = 135, ds1, CaloGAN), bf16, head_dim 80 - the instruction-lean forms of round 3.
+// Single-chunk attention (sequences of 81 .. 160 tokens = 6 .. 10 key tiles: ds2 / LEMURS T = 135, ds1 T = 88 / 125, CaloGAN T = 84), bf16, head_dim 80 - the
+// instruction-lean forms of round 3.
 // Reference: nn/vit.py:425-451 (softmax(q k^T / sqrt(dh)) v per (batch, head), token-major qkv as the qkv Linear writes it).
 //
 // What round 2's counters said about the persistent kernels of v4h_attention.hip (profiles/r03_attn_counters.md): a wave executes ~710 vector + ~430 scalar
@@ -251,7 +252,7 @@ template <int NT, int WPE, int NBUF> __global__ __launch_bounds__(64 * NT, WPE) 
 // (explicit instantiations: used only through a launcher template, the host stubs of the NBUF = 1 forms were not emitted by this hipcc)
 #define V4H_DENSE_FWD(NT, WPE, NBUF) \
   template __global__ void attn_fwd_dense_kernel<NT, WPE, NBUF>(const bf16* __restrict__, bf16* __restrict__, float* __restrict__, int, int, int, float);
-V4H_DENSE_FWD(9, 3, 2) V4H_DENSE_FWD(10, 3, 2)
+V4H_DENSE_FWD(6, 3, 2) V4H_DENSE_FWD(7, 3, 2) V4H_DENSE_FWD(8, 3, 2) V4H_DENSE_FWD(9, 3, 2) V4H_DENSE_FWD(10, 3, 2)
 #undef V4H_DENSE_FWD
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
