@@ -287,6 +287,96 @@ def sampling_rates(model, w, device, peak, batch=256, reps=2):
     return out
 
 
+def box_calibration(device):
+    """What THIS card does today on (a) a loop of nothing but bf16 MFMAs on random operands and (b) a 16-byte-per-lane copy (csrc/v4h_calib.hip):
+    the boxes of the pool differ by 2-4 % in step rate, and these two figures say which kind of box a line was measured on."""
+    from vit4hep_amd import _lib
+
+    lib = _lib.load()
+    s = _lib.stream_ptr(device)
+    blocks = 512  # two 4-wave workgroups per CU: two waves per SIMD, as in the contraction kernels
+    rnd = torch.randn(blocks * 256 * 32, device=device).to(torch.bfloat16)
+    sink = torch.zeros(64, device=device)
+    iters = 100000
+
+    def timed(fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    dt = timed(lambda: _lib.check(lib.v4h_calib_mfma_loop(_lib.ptr(rnd), _lib.ptr(sink), iters, blocks, s), "v4h_calib_mfma_loop"), 3)
+    mfma = blocks * 4 * iters * 16 * (2.0 * 16 * 16 * 32) / dt / 1e12
+    nbytes = 1 << 29  # 512 MiB each way: twice the Infinity Cache
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    dc = timed(lambda: _lib.check(lib.v4h_calib_copy(_lib.ptr(src), _lib.ptr(dst), nbytes, s), "v4h_calib_copy"), 5)
+    del src, dst
+    return {"mfma_loop_tflops": round(mfma, 1), "copy_tb_per_s": round(2.0 * nbytes / dc / 1e12, 3),
+            "note": "bf16 MFMA-only loop on random register operands (2 waves / SIMD, 0.14 s) and a 2 x 512 MiB float4 copy, measured in this run after the timed region"}
+
+
+def other_rates(mode, device):
+    """On the driver's clock too: BASELINE config 3 (ds3, bs = 64) through the fused trainer, and config 2 through the UNCHANGED-_step route - the
+    autograd node with torch.optim.AdamW, two clip_grad_norm_().cpu().item() and loss.item() per step (reference experiments/base_experiment.py:555-602)."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    out = {}
+    w = WORKLOADS["ds3"]
+    model = build_model(w, mode, device)
+    tr = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
+    x, c = synthetic(w["shape"], w["B"], seed=3, device=device, cond=w["cond"])
+    for _ in range(3):
+        tr.step(x, c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        _, gn = tr.step(x, c)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    CFMTrainer.check_finite(gn)
+    T, P = tokens_and_patch_dim(w)
+    out["ds3_b64_steps_per_s"] = round(1.0 / dt, 2)
+    out["ds3_b64_frac_of_spec_peak"] = round(3.0 * w["B"] * fwd_flops_per_sample(T, P, w["depth"], K=w["cond"]) / dt / 1e12 / (BF16_DENSE_PEAK_TFLOPS if mode == "bf16" else F32_MFMA_PEAK_TFLOPS), 4)
+    del tr, model, x, c
+    torch.cuda.empty_cache()
+
+    w = WORKLOADS["ds2"]
+    model = build_model(w, mode, device)
+    opt = torch.optim.AdamW([{"params": model.parameters(), "lr": 1e-4}], betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50000, eta_min=0)
+    x, c = synthetic(w["shape"], w["B"], seed=4, device=device, cond=w["cond"])
+    model.train()
+
+    def ref_step():  # BaseExperiment._step, line by line
+        loss = model._batch_loss([x, c])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.net.parameters(), float("inf")).cpu().item()
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1000.0, error_if_nonfinite=True).cpu().item()
+        opt.step()
+        sched.step()
+        return loss.item(), gnorm
+
+    for _ in range(3):
+        ref_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ref_step()
+    torch.cuda.synchronize()
+    out["dropin_step_steps_per_s"] = round(10.0 / (time.perf_counter() - t0), 2)
+    out["dropin_step_note"] = ("ds2 bs=128, unchanged BaseExperiment._step: autograd node + torch.optim.AdamW + CosineAnnealingLR, 2 x clip_grad_norm_().cpu().item(), "
+                               "loss.item(); 10 timed steps")
+    del opt, sched, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as fh:
@@ -348,7 +438,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-rates", action="store_true")
     ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--no-box", action="store_true", help="skip the box calibration (MFMA-only loop, copy)")
+    ap.add_argument("--no-other", action="store_true", help="skip the ds3 and drop-in-_step rates")
+    ap.add_argument("--lean", action="store_true", help="the timed region only (A/B runs): no op rates, sampling, other rates, CPU baseline; box calibration stays")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = args.no_op_rates = args.no_sampling = args.no_other = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # before anything touches the GPU in this process
 
@@ -399,15 +494,27 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    step_marks = [] if os.environ.get("V4H_BENCH_STEP_EVENTS") == "1" else None  # diagnostic: one event per step (a barrier packet each, ~0.1 %)
     for _ in range(args.steps):
         loss, gn = trainer.step(x, c)
+        if step_marks is not None:
+            step_marks.append(torch.cuda.Event(enable_timing=True))
+            step_marks[-1].record()
     e1.record()
     sync()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
+    if step_marks:
+        ts = [e0.elapsed_time(m) for m in step_marks]
+        per = [round(b - a, 3) for a, b in zip([0.0] + ts[:-1], ts)]
+        print(f"bench.py: device ms per step (rank {rank}): {per}", file=sys.stderr)
     CFMTrainer.check_finite(gn)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    rank_walls = None
     if dist.is_initialized():
+        gathered = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(gathered, tmax)
+        rank_walls = [float(g.item()) for g in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
 
@@ -441,14 +548,27 @@ def main():
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
+        rec["roofline"]["traffic_source"] = ("profiles/step_hbm_traffic.json (builder-measured PMC passes over this program, digest-matched to the kernel "
+                                             "sources of this build; not measured in this run)")
         if traffic_note:
             rec["roofline"]["traffic_note"] = traffic_note
+        if dist.is_initialized():  # self-describing N > 1 lines: what transport the ranks really used, and how far apart they finished
+            rec["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
+            rec["backend"] = dist.get_backend()
+            rec["rank_ms_per_step"] = {"min": round(min(rank_walls) * 1e3 / args.steps, 4), "max": round(max(rank_walls) * 1e3 / args.steps, 4),
+                                       "per_rank": [round(v * 1e3 / args.steps, 4) for v in rank_walls]}
         if REHEARSAL:
             rec["rehearsal"] = True  # N ranks on one GPU over gloo: a functional check of the multi-rank path, not a measurement
+        if world == 1 and not args.no_box:
+            rec["box"] = box_calibration(device)
         if world == 1 and not args.no_op_rates:
             rec["gemm_ops"] = op_rates(args.mode, B * T, device)
         if world == 1 and not args.no_sampling and args.workload == "ds2":
             rec["sampling"] = sampling_rates(model, w, device, peak)
+        if world == 1 and not args.no_other and args.workload == "ds2":
+            del trainer
+            torch.cuda.empty_cache()
+            rec["other"] = other_rates(args.mode, device)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(w)
             rec["speedup_vs_cpu"] = round(rec["value"] / rec["cpu_baseline"]["value"], 1)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 8
+#define V4H_ABI_VERSION 9
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -191,6 +191,18 @@ int32_t v4h_sq_norm_accum(const float* d_g, int64_t n, float* d_out, void* strea
  * zeroes the counter to resume.  d_gnorm_sq == NULL: no clipping and no norm guard (a non-zero counter still holds updates back). */
 int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int32_t step, void* stream, int32_t* d_nonfinite);
+/* The same update with the optimizer's step index and the learning-rate schedule position kept in DEVICE memory, so that an update the device decides to
+ * skip advances neither - the reference's `_step` returns before optimizer.step() and scheduler.step() when the gradient norm exceeds
+ * training.max_grad_norm after MIN_STEP_SKIP = 1000 iterations (experiments/base_experiment.py:31,586-591), and raises before them on a non-finite norm
+ * (:573-585).  d_state_in / d_state_out: int32[4] each, DISTINCT buffers (every thread reads the one, one thread writes the other; the caller swaps them
+ * between calls): [0] optimizer steps applied so far (torch.optim.AdamW's `step`), [1] scheduler steps so far (CosineAnnealingLR.last_epoch),
+ * [2] updates skipped because of max_grad_norm, [3] reserved.  The update uses step = state[0] + 1 for the bias corrections and
+ * lr = eta_min + (lr0 - eta_min) (1 + cos(pi state[1] / t_max)) / 2 (CosineAnnealingLR in closed form; configs/training/default.yaml:20-24), both
+ * evaluated in double.  max_grad_norm: +inf = never skip (the caller passes +inf while its iteration index is <= MIN_STEP_SKIP).  max_norm, d_gnorm_sq
+ * and d_nonfinite as in v4h_adamw_step. */
+int32_t v4h_adamw_step_sched(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr0, float eta_min,
+                             int32_t t_max, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_state_in, int32_t* d_state_out,
+                             float max_grad_norm, void* stream, int32_t* d_nonfinite);
 /* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
 int32_t v4h_axpby(float* d_out, const float* d_a, const float* d_b, float alpha, float beta, int64_t n, void* stream);
 int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const float* d_k3, const float* d_k4, float h, int64_t n, void* stream);
@@ -246,6 +258,15 @@ int32_t v4h_selected_contraction_kernel(void);
    collectives are enabled (profiles/r03_comm_interference.md). */
 int32_t v4h_reserve_compute_units(int32_t n);
 int32_t v4h_reserved_compute_units(void);
+
+/* ---- box calibration (bench.py only; nothing of the reference corresponds to these) ----------------------------------------------------------
+ * What THIS card at its clocks today does on a loop of nothing but bf16 MFMAs on random operands, and on a 16-byte-per-lane streaming copy: the
+ * two figures travel in the bench line next to the step rate, so that rates measured on different boxes of the pool (2-4 % apart) can be compared.
+ * v4h_calib_mfma_loop: `blocks` workgroups of 4 waves; every wave runs `iters` iterations of 16 v_mfma_f32_16x16x32_bf16 on operands taken from
+ * d_rnd (bf16, at least blocks * 256 * 32 elements): 2 * 16 * 16 * 32 * 16 FLOP per wave and iteration.  d_sink: 64 floats (never written in practice).
+ * v4h_calib_copy: dst[0 .. bytes) = src[0 .. bytes), bytes a multiple of 16. */
+int32_t v4h_calib_mfma_loop(const void* d_rnd, float* d_sink, int32_t iters, int32_t blocks, void* stream);
+int32_t v4h_calib_copy(const void* d_src, void* d_dst, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -77,6 +77,7 @@ SIGNATURES = {
     "v4h_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
     "v4h_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
+    "v4h_adamw_step_sched": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp]),
     "v4h_axpby": (_i32, [_vp, _vp, _vp, _f32, _f32, _i64, _vp]),
     "v4h_rk4_combine": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "v4h_op_gemm": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -94,6 +95,8 @@ SIGNATURES = {
     "v4h_selected_contraction_kernel": (_i32, []),
     "v4h_reserve_compute_units": (_i32, [_i32]),
     "v4h_reserved_compute_units": (_i32, []),
+    "v4h_calib_mfma_loop": (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    "v4h_calib_copy": (_i32, [_vp, _vp, _i64, _vp]),
 }
 # contraction kernels selectable through v4h_select_contraction_kernel (all exact)
 KERNEL_AUTO, KERNEL_TWO_WG, KERNEL_RING = 0, 1, 2

@@ -1,8 +1,17 @@
-"""One autograd node for the whole ViT: forward and backward both run inside libvit4hep_hip.so."""
+"""Autograd plumbing of the ViT: forward and backward both run inside libvit4hep_hip.so.
+
+Single process: ONE autograd node for the whole network (one forward call, one backward call).
+Under ``torch.distributed`` (the reference's ``DDP(model.net)``, experiments/base_experiment.py:161-167): the same single forward call, but a CHAIN of
+nodes - embedders, block 0 ... block depth-1, final layer - whose backward each runs one stage of the library's staged backward pass
+(include/vit4hep_hip.h: stage 0 final layer, 1+j block depth-1-j, depth+1 embedders) and returns only that stage's parameter gradients.  DDP's reducer
+hooks therefore fire stage by stage, as they do for the reference's layer-by-layer autograd graph, and its bucketed all-reduce overlaps the rest of the
+backward pass instead of starting after it.
+"""
 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -164,6 +173,112 @@ class _ViTFunction(torch.autograd.Function):
         return (None, None, None, None, None, *grads)
 
 
+# ---------------------------------------------------------------------------------------------------------------- staged nodes (data-parallel runs)
+STAGE_LOG = None  # tests: a list that receives ("stage", s) when backward stage s starts (tests/test_hip_round4.py)
+
+
+class _Pass:
+    """State shared by the nodes of one forward / backward pass."""
+
+    __slots__ = ("net", "ws", "patches_io", "params", "grads", "dout", "out", "carrier_grad", "depth")
+
+
+def _stage_param_slices(net, nparams):
+    """Positions in parameter_list() owned by each node: [embedders (+ fine-tuning mappers)], [block 0], ..., [block depth-1], [final layer]."""
+    depth = int(net.depth)
+    first = list(range(0, 11)) + list(range(11 + 10 * depth + 4, nparams))
+    blocks = [list(range(11 + 10 * i, 11 + 10 * (i + 1))) for i in range(depth)]
+    final = list(range(11 + 10 * depth, 11 + 10 * depth + 4))
+    return first, blocks, final
+
+
+def _run_stage(ps, stage):
+    if STAGE_LOG is not None:
+        STAGE_LOG.append(("stage", stage))
+    run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage)
+
+
+class _StageEmbed(torch.autograd.Function):
+    """Runs the WHOLE forward (one library call); its backward is the last stage (x / t / c embedders, positional frequencies, mappers)."""
+
+    @staticmethod
+    def forward(ctx, ps, x_vox, t, c, idx, *stage_params):
+        out, ps.ws = run_forward(ps.net, ps.params, x_vox, t, c, True)
+        ps.out = out
+        ctx.ps, ctx.idx = ps, idx
+        return torch.empty(1, dtype=torch.float32, device=x_vox.device)  # carrier: links the nodes, carries no data
+
+    @staticmethod
+    def backward(ctx, _carrier_grad):
+        ps = ctx.ps
+        _run_stage(ps, ps.depth + 1)
+        grads = [ps.grads[i] for i in ctx.idx]
+        ps.ws = ps.dout = None
+        return (None, None, None, None, None, *grads)
+
+
+class _StageBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ps, carrier, i, idx, *stage_params):
+        ctx.ps, ctx.i, ctx.idx = ps, i, idx
+        return torch.empty_like(carrier)
+
+    @staticmethod
+    def backward(ctx, _carrier_grad):
+        ps = ctx.ps
+        _run_stage(ps, 1 + (ps.depth - 1 - ctx.i))
+        return (None, ps.carrier_grad, None, None, *[ps.grads[k] for k in ctx.idx])
+
+
+class _StageFinal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ps, carrier, idx, *stage_params):
+        ctx.ps, ctx.idx = ps, idx
+        out, ps.out = ps.out, None
+        return _patchify(ps.net, out) if ps.patches_io else out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ps = ctx.ps
+        g = _lib.require_cuda(grad_out, "grad_output")
+        ps.dout = _unpatchify(ps.net, g) if ps.patches_io else g
+        sizes = [(p.numel() + 63) // 64 * 64 for p in ps.params]  # 256-byte aligned slices of one zeroed buffer
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=ps.dout.device)
+        ps.grads, off = [], 0
+        for p, n in zip(ps.params, sizes):
+            ps.grads.append(flat[off : off + p.numel()].view_as(p))
+            off += n
+        ps.carrier_grad = flat[:1]  # any defined tensor: the carriers carry no data
+        _run_stage(ps, 0)
+        return (None, ps.carrier_grad, None, *[ps.grads[k] for k in ctx.idx])
+
+
+def staged_autograd():
+    """Per-stage nodes exactly when a process group exists (V4H_STAGED_AUTOGRAD=0 / 1 overrides: A/B and tests)."""
+    e = os.environ.get("V4H_STAGED_AUTOGRAD")
+    if e in ("0", "1"):
+        return e == "1"
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
+def _apply_staged(net, x, t, c, patches_io, params):
+    x_vox = _unpatchify(net, x) if patches_io else x
+    if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):
+        raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {_vox_shape(net, x_vox.shape[0])}")
+    ps = _Pass()
+    ps.net, ps.patches_io, ps.params, ps.depth = net, patches_io, [p.detach() for p in params], int(net.depth)
+    ps.ws = ps.grads = ps.dout = ps.out = ps.carrier_grad = None
+    first, blocks, final = _stage_param_slices(net, len(params))
+    carrier = _StageEmbed.apply(ps, x_vox, t, c, first, *[params[i] for i in first])
+    for i, idx in enumerate(blocks):
+        carrier = _StageBlock.apply(ps, carrier, i, idx, *[params[k] for k in idx])
+    if not carrier.requires_grad:  # every parameter below the final layer is frozen: the chain needs no carrier
+        carrier = carrier.detach()
+    return _StageFinal.apply(ps, carrier, final, *[params[k] for k in final])
+
+
 def vit_apply(net, x, t, c, patches_io):
     x, t, c = _prep_inputs(net, x, t, c)
     params = net.parameter_list()
@@ -171,6 +286,8 @@ def vit_apply(net, x, t, c, patches_io):
         if not p.is_cuda or p.dtype != torch.float32:
             raise RuntimeError("vit4hep_amd: parameters must be float32 tensors on the MI355X device (model.to(device, torch.float32))")
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if staged_autograd():
+            return _apply_staged(net, x, t, c, patches_io, params)
         return _ViTFunction.apply(net, x, t, c, patches_io, *params)
     x_vox = _unpatchify(net, x) if patches_io else x
     if tuple(x_vox.shape) != _vox_shape(net, x_vox.shape[0]):

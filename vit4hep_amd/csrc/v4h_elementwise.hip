@@ -710,6 +710,53 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     v[i] = vi;
   }
 }
+// The same update with the optimizer's step index and the CosineAnnealingLR position kept ON THE DEVICE (reference base_experiment.py:586-597): an update
+// that is skipped - non-finite norm, or gradient norm above max_grad_norm after MIN_STEP_SKIP iterations - advances neither, exactly as the reference's
+// early `return` skips optimizer.step() and scheduler.step(); the host never has to know.  state_in = {applied optimizer steps, scheduler steps,
+// updates skipped for max_grad_norm, -}; every thread reads state_in, thread 0 of workgroup 0 writes state_out (another 16 bytes: no race with readers).
+__global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                   const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float eps, float wd,
+                                   const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm, int* nonfinite) {
+  const int applied = state_in[0], sched = state_in[1], skipped = state_in[2];
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  float coef = 1.0f;
+  const float nrm = gnorm_sq ? sqrtf(*gnorm_sq) : 0.0f;
+  const bool stuck = nonfinite && __hip_atomic_load(nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+  if (!isfinite(nrm) || stuck) {
+    if (lead) {
+      if (nonfinite) atomicAdd(nonfinite, 1);
+      state_out[0] = applied; state_out[1] = sched; state_out[2] = skipped; state_out[3] = 0;
+    }
+    return;
+  }
+  if (nrm > max_grad_norm) {  // (max_grad_norm = +inf: never)
+    if (lead) { state_out[0] = applied; state_out[1] = sched; state_out[2] = skipped + 1; state_out[3] = 0; }
+    return;
+  }
+  if (lead) { state_out[0] = applied + 1; state_out[1] = sched + 1; state_out[2] = skipped; state_out[3] = 0; }
+  // bias corrections and learning rate in double, like torch.optim.AdamW / CosineAnnealingLR on the host: one wave per workgroup computes, LDS hands out
+  __shared__ float sh[3];
+  if (threadIdx.x == 0) {
+    const double step = (double)(applied + 1);
+    const double bc1 = -expm1(step * log((double)b1)), bc2 = -expm1(step * log((double)b2));
+    const double lr = (double)eta_min + ((double)lr0 - (double)eta_min) * 0.5 * (1.0 + cos(3.14159265358979323846 * (double)sched / (double)t_max));
+    sh[0] = (float)lr; sh[1] = (float)bc1; sh[2] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float lr = sh[0], bc1 = sh[1], sqrt_bc2 = sh[2];
+  if (gnorm_sq) coef = fminf(1.0f, clip / (nrm + 1e-6f));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = m[i] * b1 + (1.0f - b1) * gi;
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
 __global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = alpha * a[i] + beta * b[i];
 }
@@ -947,6 +994,13 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
                float bc1, float bc2, int* nonfinite, hipStream_t s) {
   hipLaunchKernelGGL(adamw_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr, b1, b2, eps, wd, bc1, sqrtf(bc2), nonfinite);
   V4H_CHECK_LAUNCH("adamw");
+  return V4H_OK;
+}
+int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, hipStream_t s) {
+  hipLaunchKernelGGL(adamw_sched_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out,
+                     max_grad_norm, nonfinite);
+  V4H_CHECK_LAUNCH("adamw_sched");
   return V4H_OK;
 }
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s) {

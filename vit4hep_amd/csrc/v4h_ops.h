@@ -76,8 +76,15 @@ int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, lon
 int sq_norm_accum(const float* g, long n, float* out, hipStream_t s);  // out[0] += sum g^2 (atomic)
 int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
                float bc1, float bc2, int* nonfinite, hipStream_t s);
+// the same with the step index and the cosine-schedule position on the device (state_in / state_out: 4 ints each, distinct)
+int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, hipStream_t s);
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
 int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
+
+// ---- box calibration for bench.py (v4h_calib.hip) ----
+int calib_mfma_loop(const void* rnd_bf16, float* sink, int iters, int blocks, hipStream_t s);  // blocks x 256 lanes, each iteration 16 MFMA 16x16x32 bf16 per wave
+int calib_copy(const void* src, void* dst, long bytes, hipStream_t s);
 
 // ---- energy model, resident decoder (v4h_energy_fused.hip; bf16 mode) ----
 size_t energy_fused_stream_bytes(int nd);

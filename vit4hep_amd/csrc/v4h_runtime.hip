@@ -890,6 +890,13 @@ extern "C" int32_t v4h_adamw_step(float* p, const float* g, float* m, float* v, 
   const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
   return adamw_step(p, g, m, v, n, gnorm_sq, max_norm, lr, b1, b2, eps, wd, (float)bc1, (float)bc2, nonfinite, (hipStream_t)s);
 }
+extern "C" int32_t v4h_adamw_step_sched(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr0, float eta_min,
+                                        int32_t t_max, float b1, float b2, float eps, float wd, const int32_t* state_in, int32_t* state_out, float max_grad_norm,
+                                        void* s, int32_t* nonfinite) {
+  V4H_CHECK_ARG(p && g && m && v && n > 0 && state_in && state_out && t_max > 0, "adamw_step_sched: bad argument");
+  V4H_CHECK_ARG(state_in != state_out, "adamw_step_sched: d_state_in and d_state_out must be distinct (every thread reads the one, one thread writes the other)");
+  return adamw_step_sched(p, g, m, v, n, gnorm_sq, max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out, max_grad_norm, nonfinite, (hipStream_t)s);
+}
 extern "C" int32_t v4h_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n, void* s) {
   V4H_CHECK_ARG(out && a && b && n > 0, "axpby: bad argument");
   return axpby(out, a, b, alpha, beta, n, (hipStream_t)s);
@@ -909,6 +916,16 @@ extern "C" int32_t v4h_reserve_compute_units(int32_t n) {
   return V4H_OK;
 }
 extern "C" int32_t v4h_reserved_compute_units(void) { return v4h_reserved_cus.load(std::memory_order_relaxed); }
+
+// ------------------------------------------------------------------------------------------------ box calibration (bench.py)
+extern "C" int32_t v4h_calib_mfma_loop(const void* rnd, float* sink, int32_t iters, int32_t blocks, void* s) {
+  V4H_CHECK_ARG(rnd && sink && iters > 0 && blocks > 0 && ((uintptr_t)rnd % 16) == 0, "calib_mfma_loop: bad argument");
+  return calib_mfma_loop(rnd, sink, iters, blocks, (hipStream_t)s);
+}
+extern "C" int32_t v4h_calib_copy(const void* src, void* dst, int64_t bytes, void* s) {
+  V4H_CHECK_ARG(src && dst && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "calib_copy: bad argument");
+  return calib_copy(src, dst, (long)bytes, (hipStream_t)s);
+}
 
 // ------------------------------------------------------------------------------------------------ single operators
 extern "C" int32_t v4h_op_gemm(int32_t mode, const void* P, int32_t ldp, int32_t pks, const void* Q, int32_t ldq, int32_t qks, const float* bias, void* out,

@@ -9,6 +9,11 @@ with configs/training/default.yaml) on flat HBM buffers, without autograd and wi
   all_reduce(loss, AVG)                           (:600-601)
 
 Loss and gradient norm come back as 0-dim device tensors; call ``check_finite`` (or .item()) when the host needs them.
+
+Checkpoints: ``state_dict()`` / ``load_state_dict()`` speak the layout of the reference's checkpoint file (``{"model", "optimizer", "scheduler", "ema"}``,
+base_experiment.py:661-677): the "optimizer" entry is a ``torch.optim.AdamW.state_dict()`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in
+``model.parameters()`` order, one param group), the "scheduler" entry a ``CosineAnnealingLR.state_dict()`` - so a run of this trainer can be continued by the
+reference's ``_init_optimizer`` / ``_init_scheduler`` warm start (:374-388, :420-431) and the other way round.
 """
 
 from __future__ import annotations
@@ -31,8 +36,10 @@ def _aligned(n, a=64):
 class CFMTrainer:
     NONFINITE_MSG = "The total norm for gradients is non-finite, so it cannot be clipped."  # torch.nn.utils.clip_grad_norm_'s own text
 
+    MIN_STEP_SKIP = 1000  # base_experiment.py:31
+
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None,
-                 nonfinite_check_every=50):
+                 nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0):
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
 
         self.model = model
@@ -42,8 +49,16 @@ class CFMTrainer:
                                       "(per-module learning rates, experiment_finetuning.py:173-205)")
         self.lr, self.betas, self.eps, self.wd = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.clip = float(clip_grad_norm) if clip_grad_norm is not None else None
+        if clip_grad_value is not None:  # training.clip_grad_value (base_experiment.py:567-572; null in every shipped config, "this is dangerous!")
+            raise NotImplementedError("CFMTrainer: clip_grad_value is not built (configs/training/default.yaml: null); use the autograd node with "
+                                      "torch.nn.utils.clip_grad_value_ if a run needs it")
+        # training.max_grad_norm (base_experiment.py:586-591): after MIN_STEP_SKIP iterations an update whose (pre-clip) gradient norm exceeds it is
+        # skipped - optimizer AND scheduler stay where they are.  Decided on the device, no host sync.
+        self.max_grad_norm = float(max_grad_norm) if max_grad_norm is not None else None
+        self.eta_min = float(eta_min)
         self.iterations = int(iterations)
-        self.step_count = 0
+        self.step_count = 0  # host's count of applied updates; the device's own counters (self._state) are what the arithmetic uses
+        self.iteration = 0   # `step` of the reference's training loop: every call of step(), applied or skipped
         self.group = group
         # The reference raises on a non-finite gradient norm BEFORE optimizer.step(), also without clipping (max_norm = inf; base_experiment.py:573-585).
         # Here the update kernel skips such a step on the device and bumps a sticky counter - and while that counter is non-zero it skips (and counts)
@@ -93,13 +108,19 @@ class CFMTrainer:
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
+        # [applied optimizer steps, scheduler steps, updates skipped for max_grad_norm, -] on the device, two copies used alternately (the update kernel
+        # reads one and writes the other: include/vit4hep_hip.h, v4h_adamw_step_sched)
+        st = getattr(self, "_state", None)
+        cur = st[self._cur].to(dev) if st is not None else torch.zeros(4, dtype=torch.int32, device=dev)
+        self._state = [cur.clone(), cur.clone()]
+        self._cur = 0
 
     def _check_alias(self):
         if any(p.data_ptr() != v.data_ptr() for p, v in ((self.params[0], self.p_views[0]), (self.params[-1], self.p_views[-1]))):
-            m, v, n = self.flat_m, self.flat_v, self.step_count
-            self._flatten()  # parameters were re-allocated (e.g. model.to(...)): adopt the new storage, keep the optimizer state
+            m, v = self.flat_m, self.flat_v
+            self._flatten()  # parameters were re-allocated (e.g. model.to(...)): adopt the new storage, keep the optimizer state (and the counters)
             if m.numel() == self.flat_m.numel() and m.device == self.flat_m.device:
-                self.flat_m, self.flat_v, self.step_count = m, v, n
+                self.flat_m, self.flat_v = m, v
 
     def lr_at(self, k):
         """CosineAnnealingLR(T_max=iterations, eta_min=0) after k scheduler steps (closed form)."""
@@ -170,13 +191,17 @@ class CFMTrainer:
         self.gnorm_sq.zero_()
         _lib.check(lib.v4h_sq_norm_accum(_lib.ptr(self.flat_g), self.total, _lib.ptr(self.gnorm_sq), s), "v4h_sq_norm_accum")
         self.step_count += 1
-        lr = self.lr_at(self.step_count - 1)
+        # `step > MIN_STEP_SKIP` of the reference is the 0-based index of the training loop (base_experiment.py:475-479,586)
+        skip_above = self.max_grad_norm if (self.max_grad_norm is not None and self.iteration > self.MIN_STEP_SKIP) else float("inf")
+        self.iteration += 1
+        st_in, st_out = self._state[self._cur], self._state[self._cur ^ 1]
         _lib.check(
-            lib.v4h_adamw_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
-                               _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                               self.step_count, s, _lib.ptr(self.nonfinite)),
-            "v4h_adamw_step",
+            lib.v4h_adamw_step_sched(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
+                                     _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations,
+                                     self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite)),
+            "v4h_adamw_step_sched",
         )
+        self._cur ^= 1
         self.net.weights_epoch += 1  # parameters rewritten through raw pointers: invalidate cached operand copies (ViT.operands_current)
         out_loss = loss.clone()
         if collectives_enabled():
@@ -187,13 +212,114 @@ class CFMTrainer:
         return out_loss, self.gnorm_sq.sqrt()
 
     def raise_if_nonfinite(self):
-        """Host look at the sticky device counter of skipped (non-finite) updates: raise like the reference, with step_count and the LR schedule
-        rewound to the last update that was applied."""
+        """Host look at the sticky device counter of skipped (non-finite) updates: raise like the reference.  The optimizer's step index and the LR
+        schedule live on the device and never advanced for a skipped update; the host's ``step_count`` is re-read from there."""
         skipped = int(self.nonfinite.item())
+        self.sync_counters()
         if skipped:
             self.nonfinite.zero_()
-            self.step_count -= skipped
-            raise RuntimeError(f"{self.NONFINITE_MSG} ({skipped} update(s) skipped on the device; step_count rewound to {self.step_count})")
+            raise RuntimeError(f"{self.NONFINITE_MSG} ({skipped} update(s) skipped on the device; step_count is {self.step_count})")
+
+    def sync_counters(self):
+        """One 16-byte read: {applied optimizer steps, scheduler steps, updates skipped for max_grad_norm}; brings ``step_count`` in line."""
+        a, k, skipped, _ = (int(v) for v in self._state[self._cur].tolist())
+        self.step_count = a
+        return {"optimizer_steps": a, "scheduler_steps": k, "skipped_max_grad_norm": skipped}
+
+    @property
+    def current_lr(self):
+        """Learning rate of the NEXT update (``optimizer.param_groups[0]["lr"]`` of the reference); syncs."""
+        return self.eta_min + (self.lr - self.eta_min) * 0.5 * (1.0 + math.cos(math.pi * self.sync_counters()["scheduler_steps"] / self.iterations))
+
+    # ---------------------------------------------------------------------------------------------- checkpoints (base_experiment.py:661-677)
+    def _torch_param_order(self):
+        """Indices into the flat layout (the C ABI's parameter order) in ``model.parameters()`` order - what torch.optim.AdamW(model.parameters())
+        numbers 0..n-1.  Both orders are the state_dict() order for the shipped networks; computed rather than assumed."""
+        by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
+        order = [by_ptr[q.data_ptr()] for q in self.model.parameters() if q.data_ptr() in by_ptr]
+        if sorted(order) != list(range(len(self.params))):
+            raise RuntimeError("CFMTrainer: model.parameters() and the network's parameter list differ (a parameter outside the ViT?)")
+        return order
+
+    def optimizer_state_dict(self):
+        """``torch.optim.AdamW.state_dict()`` of this run: loadable by the reference's optimizer (base_experiment.py:374-388)."""
+        self._check_alias()
+        cnt = self.sync_counters()
+        state = {}
+        for k, i in enumerate(self._torch_param_order()):
+            o, n = self.offsets[i], self.params[i].numel()
+            state[k] = {"step": torch.tensor(float(cnt["optimizer_steps"])),
+                        "exp_avg": self.flat_m[o : o + n].view_as(self.params[i]).clone(),
+                        "exp_avg_sq": self.flat_v[o : o + n].view_as(self.params[i]).clone()}
+        group = {"lr": self.current_lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False, "foreach": None,
+                 "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True, "initial_lr": self.lr,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def scheduler_state_dict(self):
+        """``CosineAnnealingLR.state_dict()`` at this run's position (base_experiment.py:403-408)."""
+        k = self.sync_counters()["scheduler_steps"]
+        lr = self.current_lr
+        return {"T_max": self.iterations, "eta_min": self.eta_min, "base_lrs": [self.lr], "last_epoch": k, "_step_count": k + 1, "_is_initial": False,
+                "_get_lr_called_within_step": False, "_last_lr": [lr]}
+
+    def state_dict(self):
+        """The trainer's half of the reference's checkpoint file: ``{"optimizer": ..., "scheduler": ...}`` (add ``"model": model.state_dict()``)."""
+        return {"optimizer": self.optimizer_state_dict(), "scheduler": self.scheduler_state_dict()}
+
+    def checkpoint(self):
+        """The whole file the reference's ``_save_model`` writes (base_experiment.py:667-675); no EMA here."""
+        return {"model": self.model.state_dict(), **self.state_dict(), "ema": None}
+
+    def load_state_dict(self, sd):
+        """Continue from ``state_dict()`` / ``checkpoint()`` of this class, or from the "optimizer" / "scheduler" entries written by the reference's
+        torch.optim.AdamW + CosineAnnealingLR (a "model" entry, when present, is loaded into the model first)."""
+        self._check_alias()
+        if "model" in sd and sd["model"] is not None:
+            self.model.load_state_dict(sd["model"])  # in place: the parameters stay views of the flat buffer
+            self.net.weights_epoch += 1
+        opt, sch = sd.get("optimizer"), sd.get("scheduler")
+        applied = sched = None
+        if opt is not None:
+            groups = opt["param_groups"]
+            if len(groups) != 1:
+                raise NotImplementedError("CFMTrainer.load_state_dict: one parameter group only (per-module learning rates train through the autograd node)")
+            g = groups[0]
+            if g.get("amsgrad") or g.get("maximize"):
+                raise NotImplementedError("CFMTrainer.load_state_dict: amsgrad / maximize optimizers are not this update rule")
+            order = self._torch_param_order()
+            if len(g["params"]) != len(order):
+                raise ValueError(f"optimizer state has {len(g['params'])} parameters, the network {len(order)}")
+            self.betas, self.eps, self.wd = (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"]), float(g["weight_decay"])
+            self.lr = float(g.get("initial_lr", g["lr"]))
+            steps = set()
+            self.flat_m.zero_()
+            self.flat_v.zero_()
+            for k, i in enumerate(order):
+                stt = opt["state"].get(g["params"][k])
+                if stt is None:  # never updated: fresh moments
+                    continue
+                o, n = self.offsets[i], self.params[i].numel()
+                if tuple(stt["exp_avg"].shape) != tuple(self.params[i].shape):
+                    raise ValueError(f"optimizer state {k}: shape {tuple(stt['exp_avg'].shape)} does not match parameter {tuple(self.params[i].shape)}")
+                self.flat_m[o : o + n].view_as(self.params[i]).copy_(stt["exp_avg"])
+                self.flat_v[o : o + n].view_as(self.params[i]).copy_(stt["exp_avg_sq"])
+                steps.add(int(float(stt["step"])))
+            if len(steps) > 1:
+                raise NotImplementedError(f"CFMTrainer.load_state_dict: parameters with different step counts {sorted(steps)} (one fused update for all)")
+            applied = steps.pop() if steps else 0
+        if sch is not None:
+            self.iterations, self.eta_min = int(sch["T_max"]), float(sch["eta_min"])
+            self.lr = float(sch["base_lrs"][0])
+            sched = int(sch["last_epoch"])
+        cur = self._state[self._cur].tolist()
+        new = [cur[0] if applied is None else applied, cur[1] if sched is None else sched, cur[2], 0]
+        if applied is not None and sched is None:
+            new[1] = applied
+        for t in self._state:
+            t.copy_(torch.tensor(new, dtype=torch.int32))
+        self.nonfinite.zero_()
+        self.step_count = new[0]
 
     @staticmethod
     def check_finite(grad_norm):
