@@ -97,6 +97,14 @@ size_t v4h_plan_workspace_bytes(const v4h_plan* plan, int32_t B, int32_t trainin
 int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_params, const float* d_x, const float* d_t, const float* d_c,
                         float* d_out, void* d_workspace, size_t workspace_bytes, int32_t training, void* stream, const int32_t* d_patch_map,
                         const float* d_pos);
+/* Operand copies AHEAD of the next forward.  v4h_vit_forward makes, per call, the contraction-operand copies of the parameters (bf16 casts, zero-padded
+ * extents, concatenated adaLN tensors) and the positional table; a caller that knows the parameters of the NEXT forward already - the update step, right
+ * after its optimizer kernel - calls this instead: the same work is enqueued on the plan's side stream, ordered after everything on `stream` so far, and the
+ * next v4h_vit_forward on this workspace (same plan, B, training flag, parameters untouched in between) passes V4H_FWD_REUSE_OPERANDS and waits for the
+ * copies just before its first weight-consuming kernel - so the cast of the 26 M parameters (30 us) runs beside the step's head (noise, trajectory,
+ * patch gather of reference models/base_model.py:209-215) instead of in front of it.  Nothing is skipped: the same kernels, another queue. */
+int32_t v4h_vit_prepare_operands(const v4h_plan* plan, int32_t B, const void* const* d_params, void* d_workspace, size_t workspace_bytes, int32_t training,
+                                 void* stream, const float* d_pos);
 /* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
  * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
  * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce

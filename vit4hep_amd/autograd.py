@@ -66,14 +66,17 @@ def _unpatchify(net, tok):
 
 
 @_on_device_of(2)
-def run_forward(net, params, x_vox, t, c, training, ws=None):
-    """Enqueue CaloChallengeCFM.forward on voxels.  Returns (out_vox, workspace)."""
+def run_forward(net, params, x_vox, t, c, training, ws=None, reuse_operands=False):
+    """Enqueue CaloChallengeCFM.forward on voxels.  Returns (out_vox, workspace).  ``reuse_operands`` (training, caller-owned ``ws``): the operand
+    copies of exactly these parameter values are already in ``ws`` (``prepare_operands`` after the optimizer update)."""
     plan = net._get_plan()
     B = x_vox.shape[0]
     dev = x_vox.device
     if tuple(x_vox.shape) != _vox_shape(net, B):  # the kernels index by the plan's geometry: never launch on a mismatching buffer
         raise RuntimeError(f"input shape {tuple(x_vox.shape)} does not match the network geometry {_vox_shape(net, B)}")
     flags = 1 if training else 0
+    if training and ws is not None and reuse_operands:
+        flags |= 2  # V4H_FWD_REUSE_OPERANDS
     if ws is None:
         if training:
             ws = torch.empty(plan.workspace_bytes(B, True), dtype=torch.uint8, device=dev)
@@ -95,6 +98,16 @@ def run_forward(net, params, x_vox, t, c, training, ws=None):
         "v4h_vit_forward",
     )
     return out, ws
+
+
+@_on_device_of(2)
+def prepare_operands(net, params, ws, B):
+    """Operand copies + positional table of ``params`` into the training workspace ``ws`` on the plan's side stream, behind everything enqueued so far
+    (include/vit4hep_hip.h: v4h_vit_prepare_operands); the next training forward on ``ws`` with batch ``B`` may pass ``reuse_operands``."""
+    plan = net._get_plan()
+    _, pos = net.device_tables(ws.device)
+    _lib.check(_lib.load().v4h_vit_prepare_operands(plan.handle, int(B), _lib.pointer_table(params), _lib.ptr(ws), ws.numel(), 1, _lib.stream_ptr(ws.device),
+                                                    _lib.ptr(pos)), "v4h_vit_prepare_operands")
 
 
 @_on_device_of(4)

@@ -671,8 +671,8 @@ template <typename T, int NV8, bool RESID> __global__ __launch_bounds__(256) voi
                                                                                                 int D, const T* __restrict__ y, const float* __restrict__ gate,
                                                                                                 int ld_gate, float* __restrict__ x_out) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= BT) return;  // (wave-uniform)
+  // (a grid of fewer workgroups than rows / 4 walks the rows with a stride: persistent form, A/B hook V4H_LNF_GRID)
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < BT; row += gridDim.x * 4) {
   const int b = row / Tn;
   Raw8<float> xr[NV8], gr[NV8], shr[NV8], scr[NV8];
   Raw8<T> yr[NV8];
@@ -729,6 +729,7 @@ template <typename T, int NV8, bool RESID> __global__ __launch_bounds__(256) voi
   if (lane == 0) {
     if (mean) mean[row] = mu;
     if (rstd) rstd[row] = rs;
+  }
   }
 }
 
@@ -1162,7 +1163,9 @@ int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* ga
                 "ln_resid_modulate: tensors must be 16-byte aligned");
   const dim3 grid((BT + 3) / 4);
   static const bool v2 = getenv("V4H_LNF_V2") && getenv("V4H_LNF_V2")[0] == '1';  // A/B hook: the request-everything-first form (same speed in isolation)
-#define V4H_LNR8V2(TT) hipLaunchKernelGGL((ln_modulate_fwd8v2_kernel<TT, 1, true>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
+  static const int pgrid = getenv("V4H_LNF_GRID") ? atoi(getenv("V4H_LNF_GRID")) : 0;
+  const dim3 grid2(pgrid > 0 && pgrid < (BT + 3) / 4 ? pgrid : (BT + 3) / 4);
+#define V4H_LNR8V2(TT) hipLaunchKernelGGL((ln_modulate_fwd8v2_kernel<TT, 1, true>), grid2, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
   if (v2 && D <= 512) {
     if (m == MODE_BF16) V4H_LNR8V2(bf16); else V4H_LNR8V2(float);
     V4H_CHECK_LAUNCH("ln_resid_modulate_fwd");

@@ -55,6 +55,8 @@ struct v4h_plan {
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev[8] = {};
   mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
+  mutable hipEvent_t evOps = nullptr;   // operand copies made ahead of the next forward on the side stream (v4h_vit_prepare_operands)
+  mutable bool ops_pending = false;     // ... and not yet waited for by a forward
   mutable int evi = 0;
   mutable bool side_ok = false;
   mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
@@ -97,6 +99,7 @@ static int side_init(const v4h_plan& p) {
     if (hipEventCreateWithFlags(&p.ev[i], evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   for (int i = 0; i < 4; ++i)
     if (hipEventCreateWithFlags(&p.evS[i], evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
+  if (hipEventCreateWithFlags(&p.evOps, evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   p.side_ok = true;
   return V4H_OK;
 }
@@ -220,6 +223,7 @@ extern "C" void v4h_plan_destroy(v4h_plan* p) {
   if (p && p->side_ok) {
     for (int i = 0; i < 8; ++i) hipEventDestroy(p->ev[i]);
     for (int i = 0; i < 4; ++i) hipEventDestroy(p->evS[i]);
+    hipEventDestroy(p->evOps);
     hipStreamDestroy(p->side);
   }
   delete p;
@@ -454,6 +458,59 @@ static int check_common(const v4h_plan* p, int B, const void* const* params, voi
   return V4H_OK;
 }
 
+// operand copies of the weights: cast to the mode type, awkward extents zero-padded, adaLN weights / biases concatenated (layout())
+static void operand_items(const Ctx& c, std::vector<CastPadItem>& items) {
+  const v4h_plan* p = &c.p;
+  const WS& w = c.w;
+  const int D = p->D;
+  for (int i = 0; i < p->nparams(); ++i) {
+    if (!w.wop[i]) continue;
+    int rp = p->rows[i], cp = p->cols[i];
+    if (i == P_XW) cp = p->Pxpad;
+    if (p->mapper() && i == p->xmw()) { rp = p->Pxpad; cp = p->Ppad; }
+    if (i == P_C0W) cp = p->Kcpad;
+    if (p->cmapper() && i == p->cmw()) { rp = p->Kcpad; cp = p->Kcxpad; }
+    if (i == p->fin(F_LINW)) rp = p->Ppad;
+    items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
+  }
+  items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
+  for (int i = 0; i <= p->depth; ++i) {  // concatenated adaLN biases
+    const bool last = i == p->depth;
+    const int J = last ? 2 * D : 6 * D;
+    items.push_back(CastPadItem{c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB)), w.adaB + (size_t)i * 6 * D, 1, J, 1, J, 1});
+  }
+  if (p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
+  if (p->cmapper()) items.push_back(CastPadItem{c.pf(p->cmb()), w.cmb_pad, 1, p->Kc, 1, p->Kcpad, 1});
+}
+
+// Make the operand copies and the positional table of `params` in `ws` AHEAD of the next forward, on the plan's side stream: the 30 us cast of the 26 M
+// parameters then runs beside whatever the caller enqueues on `stream` next (the update step's head: noise, trajectory, patch gather - small launches that
+// use no weight), and the forward that follows - called with V4H_FWD_REUSE_OPERANDS on this very workspace, same B and training flag - waits for it just
+// before its first weight-consuming kernel.  Ordered after everything enqueued on `stream` so far (the optimizer update).
+extern "C" int32_t v4h_vit_prepare_operands(const v4h_plan* p, int32_t B, const void* const* params, void* ws, size_t ws_bytes, int32_t training, void* stream,
+                                            const float* pos) {
+  RUN(check_common(p, B, params, ws, ws_bytes, training != 0, "vit_prepare_operands"));
+  V4H_CHECK_ARG(!p->mapped || pos != nullptr, "vit_prepare_operands: a plan made by v4h_plan_create_mapped needs d_pos");
+  Ctx c{*p, B, params, WS(), (hipStream_t)stream};
+  layout(*p, B, training != 0, (char*)ws, c.w);
+  RUN(side_init(*p));
+  hipStream_t st = c.s;
+  if (g_overlap_wgrad) {
+    RUN(side_wait_main(*p, c.s));
+    st = p->side;
+  }
+  std::vector<CastPadItem> items;
+  operand_items(c, items);
+  RUN(cast_pad_many(p->mode, items.data(), (int)items.size(), st));
+  if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, c.w.pe, p->T, p->D, st));
+  else RUN(pos_embed_fwd(c.pf(P_FREQS), c.w.pe, p->pg, p->D, st));
+  if (g_overlap_wgrad) {
+    if (hipEventRecord(p->evOps, st) != hipSuccess) { v4h_set_error("vit_prepare_operands: cannot record"); return V4H_ERR_HIP; }
+    p->ops_pending = true;
+  }
+  return V4H_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* const* params, const float* x, const float* t, const float* cnd, float* out,
                                    void* ws, size_t ws_bytes, int32_t training, void* stream, const int32_t* pmap, const float* pos) {
@@ -475,24 +532,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // 0. operand copies of the weights (cast to bf16 / zero-pad awkward extents), padded condition vector
   {
     std::vector<CastPadItem> items;
-    for (int i = 0; i < p->nparams() && !reuse; ++i) {
-      if (!w.wop[i]) continue;
-      int rp = p->rows[i], cp = p->cols[i];
-      if (i == P_XW) cp = p->Pxpad;
-      if (p->mapper() && i == p->xmw()) { rp = p->Pxpad; cp = p->Ppad; }
-      if (i == P_C0W) cp = p->Kcpad;
-      if (p->cmapper() && i == p->cmw()) { rp = p->Kcpad; cp = p->Kcxpad; }
-      if (i == p->fin(F_LINW)) rp = p->Ppad;
-      items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
-    }
-    if (!reuse) items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
-    for (int i = 0; i <= p->depth && !reuse; ++i) {  // concatenated adaLN biases
-      const bool last = i == p->depth;
-      const int J = last ? 2 * D : 6 * D;
-      items.push_back(CastPadItem{c.pf(last ? p->fin(F_ADAB) : p->blk(i, B_ADAB)), w.adaB + (size_t)i * 6 * D, 1, J, 1, J, 1});
-    }
-    if (!reuse && p->mapper()) items.push_back(CastPadItem{c.pf(p->xmb()), w.xmb_pad, 1, p->Px, 1, p->Pxpad, 1});
-    if (!reuse && p->cmapper()) items.push_back(CastPadItem{c.pf(p->cmb()), w.cmb_pad, 1, p->Kc, 1, p->Kcpad, 1});
+    if (!reuse) operand_items(c, items);
     if (same_c) {}
     else if (p->cmapper()) items.push_back(CastPadItem{cnd, w.cin, B, p->Kcx, B, p->Kcxpad, 0});
     else items.push_back(CastPadItem{cnd, w.cpad, B, p->Kc, B, p->Kcpad, 0});
@@ -517,6 +557,10 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   char* patches = p->mapper() ? w.xpm : w.xp;  // (BT, Ppad) gathered voxels
   if (pmap) RUN(patchify_map(m, false, x, pmap, patches, B, p->V, T, p->P, p->Ppad, c.s));
   else RUN(patchify(m, x, patches, B, p->pg, p->P, p->Ppad, c.s));
+  if (p->ops_pending) {  // operand copies requested ahead on the side stream (v4h_vit_prepare_operands): due now (the side stream is ordered behind them anyway)
+    if (hipStreamWaitEvent(c.s, p->evOps, 0) != hipSuccess) { v4h_set_error("vit_forward: cannot wait for the operand copies"); return V4H_ERR_HIP; }
+    p->ops_pending = false;
+  }
   if (p->mapper()) {  // fine-tuning embedding mapper: xp = silu(patches Wm^T + bm)   (experiment_finetuning.py:80-91)
     GemmArgs a = gargs(w.xpm, p->Ppad, c.W(p->xmw()), p->Ppad, BT, p->Pxpad, p->Ppad);
     a.e.out = w.xp; a.e.ldo = p->Pxpad; a.e.out2 = training ? w.xpre : nullptr; a.e.ldo2 = p->Pxpad; a.e.bias = (const float*)w.xmb_pad;

@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .autograd import run_backward, run_backward_events, run_forward
+from .autograd import prepare_operands, run_backward, run_backward_events, run_forward
 from .parallel import BucketReducer, collectives_enabled, world
 
 
@@ -108,6 +108,13 @@ class CFMTrainer:
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
+        self.use_graph = os.environ.get("V4H_STEP_GRAPH") == "1"
+        self._graph, self._graph_warm, self._in_capture = None, 0, False
+        self._ws = None  # one training workspace kept across steps (2.6 GB at ds2 bs 128)
+        # The operand copies of the weights (bf16 casts of 26 M parameters, 30 us) are requested on the library's side stream at the very start of a step
+        # and the forward waits for them only in front of its first weight-consuming kernel: they run beside the step's head (noise, trajectory, patch
+        # gather) instead of in front of the first contraction.  V4H_PREPARE_AHEAD=0: inside the forward, as the autograd route does (A/B hook).
+        self.prepare_ahead = os.environ.get("V4H_PREPARE_AHEAD", "1") != "0"
         # [applied optimizer steps, scheduler steps, updates skipped for max_grad_norm, -] on the device, two copies used alternately (the update kernel
         # reads one and writes the other: include/vit4hep_hip.h, v4h_adamw_step_sched)
         st = getattr(self, "_state", None)
@@ -139,6 +146,11 @@ class CFMTrainer:
         x = _lib.require_cuda(x, "x")
         c = _lib.require_cuda(c, "c")
         B = x.shape[0]
+        need = self.net._get_plan().workspace_bytes(B, True)
+        if self._ws is None or self._ws.numel() != need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self.prepare_ahead:
+            prepare_operands(self.net, self.p_views, self._ws, B)
         if t is None:  # reference: CPU generator for t, device generator for x_0 (models/base_model.py:209-212)
             t = self.model.time_distribution.sample([B] + [1] * (x.dim() - 1)).to(dev, torch.float32, non_blocking=True)
         if x0 is None:
@@ -148,7 +160,7 @@ class CFMTrainer:
         s = _lib.stream_ptr(dev)
         xt, target = torch.empty_like(x), torch.empty_like(x)
         _lib.check(lib.v4h_cfm_prepare(_lib.ptr(x), _lib.ptr(x0), _lib.ptr(t), _lib.ptr(xt), _lib.ptr(target), B, x[0].numel(), s), "v4h_cfm_prepare")
-        v, ws = run_forward(self.net, self.p_views, xt, t, c, True)
+        v, ws = run_forward(self.net, self.p_views, xt, t, c, True, ws=self._ws, reuse_operands=self.prepare_ahead)
         dv = torch.empty_like(v)
         _lib.check(lib.v4h_mse_loss(_lib.ptr(v), _lib.ptr(target), _lib.ptr(self.loss), _lib.ptr(dv), v.numel(), s), "v4h_mse_loss")
         W = world()
@@ -182,7 +194,53 @@ class CFMTrainer:
     def step(self, x, c, t=None, x0=None):
         """One BaseExperiment._step.  Returns (loss, grad_norm) as 0-dim device tensors (pre-clip norm, like clip_grad_norm_)."""
         with _lib.on_device(self.flat_p):
+            if self.use_graph and t is None and x0 is None and self.max_grad_norm is None and not collectives_enabled():
+                return self._step_graphed(x, c)
             return self._step(x, c, t, x0)
+
+    # ---------------------------------------------------------------------------------------------- whole step as one hipGraph (opt-in)
+    def _step_graphed(self, x, c):
+        """The whole update - noise, trajectory, forward, two-stream backward, norm, AdamW - captured once into a hipGraph and replayed: the optimizer's
+        step index and LR position live on the device (v4h_adamw_step_sched), so no kernel argument changes between replays; only t (sampled on the host
+        generator like the reference, models/base_model.py:209-211) is copied into its static buffer first.  The returned tensors are the graph's own
+        (overwritten by the next replay).  Opt-in (V4H_STEP_GRAPH=1 / use_graph): measured against the eager launch sequence in DESIGN.md."""
+        self._check_alias()
+        x = _lib.require_cuda(x, "x")
+        c = _lib.require_cuda(c, "c")
+        key = (tuple(x.shape), tuple(c.shape), self.flat_p.data_ptr())
+        g = self._graph
+        if g is None or g["key"] != key:
+            if self._graph_warm < 2 or (g is not None and g["key"] != key):  # lazy initialisation (streams, LDS attributes, workspace) outside a capture
+                self._graph_warm += 1
+                self._graph = None
+                return self._step(x, c, None, None)
+            B = x.shape[0]
+            g = {"key": key, "x": x.clone(), "c": c.clone(), "t": torch.empty([B] + [1] * (x.dim() - 1), dtype=torch.float32, device=x.device)}
+            g["t"].copy_(self.model.time_distribution.sample(list(g["t"].shape)))
+            self._in_capture = True
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    g["out"] = self._step(g["x"], g["c"], g["t"], None)
+            finally:
+                self._in_capture = False
+            g["graph"] = graph
+            self._graph = g
+            # (the capture enqueued nothing: the counters the captured _step advanced on the host are advanced for real by the replay below)
+            self.step_count -= 1
+            self.iteration -= 1
+        if g["x"].data_ptr() != x.data_ptr():
+            g["x"].copy_(x, non_blocking=True)
+        if g["c"].data_ptr() != c.data_ptr():
+            g["c"].copy_(c, non_blocking=True)
+        g["t"].copy_(self.model.time_distribution.sample(list(g["t"].shape)), non_blocking=True)
+        g["graph"].replay()
+        self.step_count += 1
+        self.iteration += 1
+        self.net.weights_epoch += 1
+        if self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
+            self.raise_if_nonfinite()
+        return g["out"]
 
     def _step(self, x, c, t, x0):
         lib = _lib.load()
@@ -195,19 +253,23 @@ class CFMTrainer:
         skip_above = self.max_grad_norm if (self.max_grad_norm is not None and self.iteration > self.MIN_STEP_SKIP) else float("inf")
         self.iteration += 1
         st_in, st_out = self._state[self._cur], self._state[self._cur ^ 1]
+        capturing = getattr(self, "_in_capture", False)
         _lib.check(
             lib.v4h_adamw_step_sched(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
                                      _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations,
                                      self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite)),
             "v4h_adamw_step_sched",
         )
-        self._cur ^= 1
+        if capturing:  # a replayed graph has fixed pointers: copy the new counters back instead of swapping the two buffers
+            st_in.copy_(st_out)
+        else:
+            self._cur ^= 1
         self.net.weights_epoch += 1  # parameters rewritten through raw pointers: invalidate cached operand copies (ViT.operands_current)
         out_loss = loss.clone()
         if collectives_enabled():
             dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
             out_loss /= world()
-        if self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
+        if not capturing and self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
             self.raise_if_nonfinite()
         return out_loss, self.gnorm_sq.sqrt()
 
