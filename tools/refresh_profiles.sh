@@ -41,7 +41,11 @@ for w in ds3 ds2_d2 lemurs ds1_photons ds1_pions calogan calohad; do
 done
 python3 bench.py --mode f32 --steps 10 --warmup 3 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_f32.json
 V4H_FORCE_COLLECTIVES=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_forced_collectives.json 2> $out/forced_collectives.err || echo "forced-collectives run failed"
-[ -f vit4hep_amd/libvit4hep_hip_abl.so ] && VIT4HEP_AMD_LIB=$PWD/vit4hep_amd/libvit4hep_hip_abl.so ABL=1 python3 tools/gemm2_bench.py > $out/gemm2_ablation.txt 2>&1 || true
+# (the ablation build does not travel to the GPU box - .gpurunignore - and is made here, on request: ABL_BENCH=1)
+if [ "${ABL_BENCH:-0}" = "1" ]; then
+  V4H_BUILD_TAG=abl V4H_EXTRA_FLAGS=-DV4H_ABLATIONS python3 -m vit4hep_amd.build > $out/abl_build.log 2>&1 && \
+  VIT4HEP_AMD_LIB=$PWD/vit4hep_amd/libvit4hep_hip_abl.so ABL=1 python3 tools/gemm2_bench.py > $out/gemm2_ablation.txt 2>&1 || true
+fi
 fi
 if has 3; then
 # in-context A/B of the alternatives that are kept behind switches (interleaved, same box)

@@ -57,6 +57,7 @@ struct v4h_plan {
   mutable hipEvent_t evS[4] = {};  // side-stream progress marks (after the fc2 / fc1 / proj / qkv weight gradient of a block, after an adaLN backward)
   mutable hipEvent_t evOps = nullptr;   // operand copies made ahead of the next forward on the side stream (v4h_vit_prepare_operands)
   mutable bool ops_pending = false;     // ... and not yet waited for by a forward
+  mutable unsigned mark_live = 0;       // side-stream marks recorded by the backward call in progress
   mutable int evi = 0;
   mutable bool side_ok = false;
   mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
@@ -131,9 +132,13 @@ static int main_wait_side(const v4h_plan& p, hipStream_t main) {
 enum { S_FC2 = 0, S_ADA, S_BLK0, S_BLK1 };
 static int side_mark(const v4h_plan& p, int which) {
   if (hipEventRecord(p.evS[which], p.side) != hipSuccess) { v4h_set_error("mark failed"); return V4H_ERR_HIP; }
+  p.mark_live |= 1u << which;
   return V4H_OK;
 }
+// Only marks dropped by THIS call are waited for: every backward call ends with a full join of the two streams, so an older mark is long reached - and a
+// stream that is being captured into a hipGraph must not wait for an event recorded outside the capture.
 static int main_wait_mark(const v4h_plan& p, int which, hipStream_t main) {
+  if (!(p.mark_live & (1u << which))) return V4H_OK;
   if (hipStreamWaitEvent(main, p.evS[which], 0) != hipSuccess) { v4h_set_error("wait for mark failed"); return V4H_ERR_HIP; }
   return V4H_OK;
 }
@@ -711,6 +716,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   const Mode m = p->mode;
   const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
   RUN(side_init(*p));
+  p->mark_live = 0;
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
   auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
   // A backward pass issued as ONE call handles every adaLN Linear of the step together at the end (one cast, one grouped weight-gradient
