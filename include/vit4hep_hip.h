@@ -206,7 +206,7 @@ int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int
  * between calls): [0] optimizer steps applied so far (torch.optim.AdamW's `step`), [1] scheduler steps so far (CosineAnnealingLR.last_epoch),
  * [2] updates skipped because of max_grad_norm, [3] reserved.  The update uses step = state[0] + 1 for the bias corrections and
  * lr = eta_min + (lr0 - eta_min) (1 + cos(pi state[1] / t_max)) / 2 (CosineAnnealingLR in closed form; configs/training/default.yaml:20-24), both
- * evaluated in double.  max_grad_norm: +inf = never skip (the caller passes +inf while its iteration index is <= MIN_STEP_SKIP).  max_norm, d_gnorm_sq
+ * accurate to f32 rounding (1 - beta^step as -expm1(step log beta) with log beta taken in double on the host).  max_grad_norm: +inf = never skip (the caller passes +inf while its iteration index is <= MIN_STEP_SKIP).  max_norm, d_gnorm_sq
  * and d_nonfinite as in v4h_adamw_step. */
 int32_t v4h_adamw_step_sched(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr0, float eta_min,
                              int32_t t_max, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_state_in, int32_t* d_state_out,

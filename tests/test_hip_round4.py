@@ -64,8 +64,9 @@ def test_trainer_checkpoint_resumes_in_trainer_and_in_torch_adamw():
     assert all(float(s["step"]) == 5.0 for s in ck["optimizer"]["state"].values())
     assert len(ck["optimizer"]["state"]) == len(list(model1.parameters())) == len(ck["optimizer"]["param_groups"][0]["params"])
 
-    # losses / gradient norms to f32 rounding; weights to 1e-4 of the tensor's scale: the conditioning-path gradients are sums of f32 atomics whose order
-    # varies from run to run, and Adam turns a last-bit difference of a tiny gradient into +-lr (the uninterrupted run against ITSELF differs as much)
+    # losses / gradient norms to f32 rounding; weights to 1e-3 of the tensor's scale: the conditioning-path gradients are sums of f32 atomics whose order
+    # varies from run to run, and Adam turns a last-bit difference of a near-zero gradient into +-lr per step (the uninterrupted run against ITSELF
+    # differs by 0.5 - 1.3e-4 on c_embedder.0.weight over these 10 steps).  What the file must carry exactly is checked bit for bit right after loading.
     def close(losses, norms, weights, tol_l, tol_w, who):
         assert np.allclose(losses, ref_l[5:], rtol=tol_l), (who, losses, ref_l[5:])
         assert np.allclose(norms, ref_n[5:], rtol=10 * tol_l), (who, norms, ref_n[5:])
@@ -77,8 +78,10 @@ def test_trainer_checkpoint_resumes_in_trainer_and_in_torch_adamw():
     tr2 = CFMTrainer(model2, lr=3e-3, betas=(0.5, 0.9), weight_decay=0.0, iterations=7)
     tr2.load_state_dict(ck)
     assert tr2.sync_counters() == {"optimizer_steps": 5, "scheduler_steps": 5, "skipped_max_grad_norm": 0}
+    assert torch.equal(tr2.flat_m, tr1.flat_m) and torch.equal(tr2.flat_v, tr1.flat_v) and torch.equal(tr2.flat_p, tr1.flat_p)
+    assert (tr2.lr, tr2.betas, tr2.eps, tr2.wd, tr2.iterations) == (tr1.lr, tr1.betas, tr1.eps, tr1.wd, tr1.iterations)
     out = [tr2.step(x, c, t, x0) for t, x0 in noise[5:]]
-    close([float(l) for l, _ in out], [float(n) for _, n in out], model2.state_dict(), 1e-6, 1e-4, "trainer")
+    close([float(l) for l, _ in out], [float(n) for _, n in out], model2.state_dict(), 1e-6, 1e-3, "trainer")
 
     # (ii) the reference's own optimizer and scheduler objects, warm-started from the file, on the unchanged-_step route
     model3 = U.build_models(cfg, "f32", fill)
@@ -88,7 +91,7 @@ def test_trainer_checkpoint_resumes_in_trainer_and_in_torch_adamw():
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=T_MAX, eta_min=0)
     sched.load_state_dict(ck["scheduler"])
     out = [_reference_step(model3, opt, sched, x, c, t, x0) for t, x0 in noise[5:]]
-    close([l for l, _ in out], [n for _, n in out], model3.state_dict(), 2e-6, 1e-4, "torch.optim.AdamW")
+    close([l for l, _ in out], [n for _, n in out], model3.state_dict(), 2e-6, 1e-3, "torch.optim.AdamW")
 
     # (iii) torch -> trainer: 5 reference steps from scratch, its state_dict()s into a fresh CFMTrainer
     model4 = U.build_models(cfg, "f32", fill)
@@ -99,7 +102,7 @@ def test_trainer_checkpoint_resumes_in_trainer_and_in_torch_adamw():
     tr4 = CFMTrainer(model4, iterations=3)
     tr4.load_state_dict({"optimizer": opt4.state_dict(), "scheduler": sched4.state_dict()})
     out = [tr4.step(x, c, t, x0) for t, x0 in noise[5:]]
-    close([float(l) for l, _ in out], [float(n) for _, n in out], model4.state_dict(), 2e-6, 1e-4, "torch -> trainer")
+    close([float(l) for l, _ in out], [float(n) for _, n in out], model4.state_dict(), 2e-6, 1e-3, "torch -> trainer")
 
 
 def test_max_grad_norm_skips_updates_on_the_device_and_clip_grad_value_raises():

@@ -11,7 +11,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   name=$(echo $c | tr ' ' '+')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$name -- python3 $root/bench.py --steps $steps --warmup 1 --no-cpu-baseline --no-op-rates --no-sampling > $out/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$name -- python3 $root/bench.py --steps $steps --warmup 1 --lean --no-box > $out/$name.log 2>&1 || echo "pass $name failed"
   echo "pass $name done"
 done
 cd $root && python3 tools/pmc_step_summary.py $((steps + 1)) $tag > $out/summary.txt 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 baseline: how the driver's short run (--steps 20 --warmup 5) compares with the builder's longer A/B runs on one box, per-step device times, K-split A/B
 out=gpurun_out/r04a; mkdir -p $out
-B="--no-cpu-baseline --no-op-rates --no-sampling"
+B="--lean --no-box"
 val() { grep -o '"value": [0-9.]*' $1 | head -1; }
 for i in 1 2 3; do
   python3 bench.py --steps 20 --warmup 5 $B > $out/d_$i.json 2> $out/d_$i.err || exit 1; echo "20/5 run $i: $(val $out/d_$i.json)"

@@ -20,27 +20,27 @@ rm -rf gpurun_out/pmc_step/*/
 echo "pmc done"
 python3 bench.py --steps 60 --warmup 10 > $out/bench_final_bf16.json
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ovl -o p -- python3 bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/prof_ovl.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ovl -o p -- python3 bench.py --steps 12 --warmup 5 --lean --no-box > $out/prof_ovl.log 2>&1
 python3 tools/profile_summary.py $out/prof_ovl 17 $out/step_overlapped.md > /dev/null
 python3 tools/gap_analysis.py $out/prof_ovl 17 > $out/step_gaps.txt
 python3 tools/timeline.py $out/prof_ovl 3 > $out/step_timeline.txt
 echo "overlapped profile done"
-V4H_WGRAD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ser -o p -- python3 bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/prof_ser.log 2>&1
+V4H_WGRAD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ser -o p -- python3 bench.py --steps 12 --warmup 5 --lean --no-box > $out/prof_ser.log 2>&1
 python3 tools/profile_summary.py $out/prof_ser 17 $out/step_serialized.md > /dev/null
 echo "serialized profile done"
 rm -rf $out/prof_ovl/*/*_kernel_trace.csv $out/prof_ser/*/*_kernel_trace.csv $out/prof_ovl/*_kernel_trace.csv $out/prof_ser/*_kernel_trace.csv 2>/dev/null || true
 fi
 if has 2; then
-V4H_WGRAD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ds3 -o p -- python3 bench.py --workload ds3 --steps 8 --warmup 3 --no-cpu-baseline --no-op-rates --no-sampling > $out/prof_ds3.log 2>&1
+V4H_WGRAD_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_ds3 -o p -- python3 bench.py --workload ds3 --steps 8 --warmup 3 --lean --no-box > $out/prof_ds3.log 2>&1
 python3 tools/profile_summary.py $out/prof_ds3 11 $out/ds3_step_serialized.md > /dev/null
 rm -rf $out/prof_ds3/*/*_kernel_trace.csv $out/prof_ds3/*_kernel_trace.csv 2>/dev/null || true
 echo "ds3 profile done"
 for w in ds3 ds2_d2 lemurs ds1_photons ds1_pions calogan calohad; do
-  python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-op-rates > $out/bench_$w.json
+  python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-op-rates --no-other --no-box > $out/bench_$w.json
   echo "workload $w done"
 done
-python3 bench.py --mode f32 --steps 10 --warmup 3 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_f32.json
-V4H_FORCE_COLLECTIVES=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-op-rates --no-sampling > $out/bench_ds2_forced_collectives.json 2> $out/forced_collectives.err || echo "forced-collectives run failed"
+python3 bench.py --mode f32 --steps 10 --warmup 3 --lean --no-box > $out/bench_ds2_f32.json
+V4H_FORCE_COLLECTIVES=1 python3 bench.py --steps 30 --warmup 5 --lean --no-box > $out/bench_ds2_forced_collectives.json 2> $out/forced_collectives.err || echo "forced-collectives run failed"
 # (the ablation build does not travel to the GPU box - .gpurunignore - and is made here, on request: ABL_BENCH=1)
 if [ "${ABL_BENCH:-0}" = "1" ]; then
   V4H_BUILD_TAG=abl V4H_EXTRA_FLAGS=-DV4H_ABLATIONS python3 -m vit4hep_amd.build > $out/abl_build.log 2>&1 && \
@@ -52,7 +52,7 @@ if has 3; then
 for r in 1 2; do
   for v in "V4H_GEMM2=-1" "V4H_GEMM2=0" "V4H_GEMM2=8" "V4H_GEMM2_PP=61" "V4H_GEMM2_PP=55" "V4H_GEMM2_PP=63" "V4H_GEMM_SMALL=0" "V4H_ATTN_DENSE=0" "V4H_WGRAD_WGS=256" "V4H_BATCH_ADALN=0" "V4H_WGRAD_OVERLAP=0"; do
     echo -n "$v  " >> $out/ab_in_context.txt
-    env $v python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-op-rates 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], 'steps/s', r['ms_per_step'], 'ms', r['sampling']['rk4']['showers_per_s'], 'showers/s (RK4)')" >> $out/ab_in_context.txt
+    env $v python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-op-rates --no-other --no-box 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], 'steps/s', r['ms_per_step'], 'ms', r['sampling']['rk4']['showers_per_s'], 'showers/s (RK4)')" >> $out/ab_in_context.txt
   done
 done
 echo "A/B done"

@@ -945,8 +945,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // early `return` skips optimizer.step() and scheduler.step(); the host never has to know.  state_in = {applied optimizer steps, scheduler steps,
 // updates skipped for max_grad_norm, -}; every thread reads state_in, thread 0 of workgroup 0 writes state_out (another 16 bytes: no race with readers).
 __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                                   const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float eps, float wd,
-                                   const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm, int* nonfinite) {
+                                   const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float log_b1,
+                                   float log_b2, float eps, float wd, const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm,
+                                   int* nonfinite) {
   const int applied = state_in[0], sched = state_in[1], skipped = state_in[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   float coef = 1.0f;
@@ -964,16 +965,13 @@ __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restric
     return;
   }
   if (lead) { state_out[0] = applied + 1; state_out[1] = sched + 1; state_out[2] = skipped; state_out[3] = 0; }
-  // bias corrections and learning rate in double, like torch.optim.AdamW / CosineAnnealingLR on the host: one wave per workgroup computes, LDS hands out
-  __shared__ float sh[3];
-  if (threadIdx.x == 0) {
-    const double step = (double)(applied + 1);
-    const double bc1 = -expm1(step * log((double)b1)), bc2 = -expm1(step * log((double)b2));
-    const double lr = (double)eta_min + ((double)lr0 - (double)eta_min) * 0.5 * (1.0 + cos(3.14159265358979323846 * (double)sched / (double)t_max));
-    sh[0] = (float)lr; sh[1] = (float)bc1; sh[2] = (float)sqrt(bc2);
-  }
-  __syncthreads();
-  const float lr = sh[0], bc1 = sh[1], sqrt_bc2 = sh[2];
+  // Bias corrections 1 - beta^step and the cosine learning rate, per thread, in f32 - accurate to f32 rounding because the host passes log(beta) rounded
+  // from double and expm1f keeps the relative accuracy of a small argument (1 - 0.999^1 = 1e-3 would lose four digits as 1 - powf).  [First form: one
+  // thread per workgroup in double + LDS broadcast - software double transcendentals in front of every workgroup's first load made the kernel 17 us
+  // slower (132.6 vs 115.0 us, profiles/r04_*).]
+  const float stepf = (float)(applied + 1);
+  const float bc1 = -expm1f(stepf * log_b1), sqrt_bc2 = sqrtf(-expm1f(stepf * log_b2));
+  const float lr = eta_min + (lr0 - eta_min) * 0.5f * (1.0f + cospif((float)sched / (float)t_max));
   if (gnorm_sq) coef = fminf(1.0f, clip / (nrm + 1e-6f));
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
@@ -1270,8 +1268,8 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
 }
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
                      float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, hipStream_t s) {
-  hipLaunchKernelGGL(adamw_sched_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out,
-                     max_grad_norm, nonfinite);
+  hipLaunchKernelGGL(adamw_sched_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr0, eta_min, t_max, b1, b2, (float)log((double)b1),
+                     (float)log((double)b2), eps, wd, state_in, state_out, max_grad_norm, nonfinite);
   V4H_CHECK_LAUNCH("adamw_sched");
   return V4H_OK;
 }

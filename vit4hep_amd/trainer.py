@@ -108,6 +108,8 @@ class CFMTrainer:
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
+        self._t_ring, self._t_i = None, 0
+        self.async_t = os.environ.get("V4H_ASYNC_T", "1") != "0"  # A/B hook: 0 = the reference's pageable .to(device) (a host sync per step)
         self.use_graph = os.environ.get("V4H_STEP_GRAPH") == "1"
         self._graph, self._graph_warm, self._in_capture = None, 0, False
         self._ws = None  # one training workspace kept across steps (2.6 GB at ds2 bs 128)
@@ -128,6 +130,27 @@ class CFMTrainer:
             self._flatten()  # parameters were re-allocated (e.g. model.to(...)): adopt the new storage, keep the optimizer state (and the counters)
             if m.numel() == self.flat_m.numel() and m.device == self.flat_m.device:
                 self.flat_m, self.flat_v = m, v
+
+    T_RING = 4
+
+    def _stage_t(self, t_host, dev):
+        """Host-sampled times to the device WITHOUT stopping the host: a `.to(device)` from pageable memory is a synchronous copy, i.e. the host waits for
+        the previous step's last kernel at the top of every step and then issues the step's first dozen small launches one launch latency apart while
+        the GPU idles between them (the head of the step measured 130 us for 80 us of kernels).  Through a small ring of pinned buffers the copy is truly
+        asynchronous and the host runs ahead of the device (by at most T_RING steps: a buffer is reused only after its copy has completed)."""
+        n = t_host.numel()
+        if self._t_ring is None or self._t_ring[0][0].numel() < n:
+            self._t_ring = [[torch.empty(n, dtype=torch.float32).pin_memory(), None] for _ in range(self.T_RING)]
+        slot = self._t_ring[self._t_i % self.T_RING]
+        self._t_i += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:n].copy_(t_host.reshape(-1).to(torch.float32))
+        t = torch.empty(n, dtype=torch.float32, device=dev)
+        t.copy_(slot[0][:n], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return t
 
     def lr_at(self, k):
         """CosineAnnealingLR(T_max=iterations, eta_min=0) after k scheduler steps (closed form)."""
@@ -152,7 +175,8 @@ class CFMTrainer:
         if self.prepare_ahead:
             prepare_operands(self.net, self.p_views, self._ws, B)
         if t is None:  # reference: CPU generator for t, device generator for x_0 (models/base_model.py:209-212)
-            t = self.model.time_distribution.sample([B] + [1] * (x.dim() - 1)).to(dev, torch.float32, non_blocking=True)
+            t_host = self.model.time_distribution.sample([B] + [1] * (x.dim() - 1))
+            t = self._stage_t(t_host, dev) if self.async_t else t_host.to(dev, torch.float32, non_blocking=True)
         if x0 is None:
             x0 = torch.randn_like(x)
         t = _lib.require_cuda(t, "t").reshape(-1)
