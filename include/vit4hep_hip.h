@@ -188,6 +188,11 @@ int32_t v4h_shape_postprocess(const v4h_chain_spec* spec, const int32_t* d_layer
 int32_t v4h_cfm_prepare(const float* d_x1, const float* d_x0, const float* d_t, float* d_xt, float* d_target, int32_t B, int64_t per_sample, void* stream);
 /* loss = mean((v - target)^2) (models/base_model.py:217-218); d_dv (optional) = d loss / d v */
 int32_t v4h_mse_loss(const float* d_v, const float* d_target, float* d_loss, float* d_dv, int64_t n, void* stream);
+/* The same two for an update loop without fill launches (each is 5 us of serial stream time): v4h_cfm_prepare_z additionally sets *d_zero0 and *d_zero1
+ * (optional device scalars: the step's loss and squared-norm accumulators) to 0; v4h_mse_loss_acc ADDS the loss into *d_loss instead of overwriting it. */
+int32_t v4h_cfm_prepare_z(const float* d_x1, const float* d_x0, const float* d_t, float* d_xt, float* d_target, int32_t B, int64_t per_sample, void* stream,
+                          float* d_zero0, float* d_zero1);
+int32_t v4h_mse_loss_acc(const float* d_v, const float* d_target, float* d_loss, float* d_dv, int64_t n, void* stream);
 /* sum of squares accumulated into d_out[0] (clip_grad_norm_, experiments/base_experiment.py:562-585) */
 int32_t v4h_sq_norm_accum(const float* d_g, int64_t n, float* d_out, void* stream);
 /* clip_grad_norm_(max_norm) + torch.optim.AdamW step on one flat tensor (experiments/base_experiment.py:573-592,
@@ -207,10 +212,10 @@ int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int
  * [2] updates skipped because of max_grad_norm, [3] reserved.  The update uses step = state[0] + 1 for the bias corrections and
  * lr = eta_min + (lr0 - eta_min) (1 + cos(pi state[1] / t_max)) / 2 (CosineAnnealingLR in closed form; configs/training/default.yaml:20-24), both
  * accurate to f32 rounding (1 - beta^step as -expm1(step log beta) with log beta taken in double on the host).  max_grad_norm: +inf = never skip (the caller passes +inf while its iteration index is <= MIN_STEP_SKIP).  max_norm, d_gnorm_sq
- * and d_nonfinite as in v4h_adamw_step. */
+ * and d_nonfinite as in v4h_adamw_step.  d_gnorm_out (optional): receives sqrt(*d_gnorm_sq), the pre-clip norm clip_grad_norm_ returns. */
 int32_t v4h_adamw_step_sched(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr0, float eta_min,
                              int32_t t_max, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_state_in, int32_t* d_state_out,
-                             float max_grad_norm, void* stream, int32_t* d_nonfinite);
+                             float max_grad_norm, void* stream, int32_t* d_nonfinite, float* d_gnorm_out);
 /* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
 int32_t v4h_axpby(float* d_out, const float* d_a, const float* d_b, float alpha, float beta, int64_t n, void* stream);
 int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const float* d_k3, const float* d_k4, float h, int64_t n, void* stream);

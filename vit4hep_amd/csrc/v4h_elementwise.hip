@@ -865,8 +865,12 @@ template <typename T> __global__ void silu_bwd_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------ CFM step
 // linear_trajectory (models/trajectories.py:5-8) as used by CFM._batch_loss (models/base_model.py:209-215)
 __global__ void cfm_prepare_kernel(const float* __restrict__ x1, const float* __restrict__ x0, const float* __restrict__ t, float* __restrict__ xt,
-                                   float* __restrict__ target, int B, int per) {
+                                   float* __restrict__ target, int B, int per, float* zero0, float* zero1) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {  // the step's two scalar accumulators (loss, squared gradient norm) start from zero here instead of in a fill launch each
+    if (zero0) *zero0 = 0.f;
+    if (zero1) *zero1 = 0.f;
+  }
   if (i >= (long)B * per) return;
   const float tt = t[i / per];
   const float a = x0[i], b = x1[i];
@@ -947,11 +951,12 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                    const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float log_b1,
                                    float log_b2, float eps, float wd, const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm,
-                                   int* nonfinite) {
+                                   int* nonfinite, float* __restrict__ gnorm_out) {
   const int applied = state_in[0], sched = state_in[1], skipped = state_in[2];
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   float coef = 1.0f;
   const float nrm = gnorm_sq ? sqrtf(*gnorm_sq) : 0.0f;
+  if (lead && gnorm_out) *gnorm_out = nrm;  // the pre-clip norm clip_grad_norm_ returns (base_experiment.py:573-585), without a sqrt launch of its own
   const bool stuck = nonfinite && __hip_atomic_load(nonfinite, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
   if (!isfinite(nrm) || stuck) {
     if (lead) {
@@ -1239,15 +1244,17 @@ int silu_bwd(Mode m, const float* dsilu, const float* pre, void* out, int n, hip
   V4H_CHECK_LAUNCH("silu_bwd");
   return V4H_OK;
 }
-int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per, hipStream_t s) {
+int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per, hipStream_t s, float* zero0, float* zero1) {
   const long n = (long)B * per;
-  hipLaunchKernelGGL(cfm_prepare_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x1, x0, t, xt, target, B, per);
+  hipLaunchKernelGGL(cfm_prepare_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, x1, x0, t, xt, target, B, per, zero0, zero1);
   V4H_CHECK_LAUNCH("cfm_prepare");
   return V4H_OK;
 }
-int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-  if (e != hipSuccess) { v4h_set_error("mse: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s, bool zero_first) {
+  if (zero_first) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (e != hipSuccess) { v4h_set_error("mse: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+  }
   hipLaunchKernelGGL(mse_kernel, dim3(nblocks(n, 1024, 256)), dim3(256), 0, s, v, target, loss, dv, n, 1.0f / (float)n);  // (same-address atomic per workgroup)
   V4H_CHECK_LAUNCH("mse");
   return V4H_OK;
@@ -1267,9 +1274,9 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
   return V4H_OK;
 }
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
-                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, hipStream_t s) {
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s) {
   hipLaunchKernelGGL(adamw_sched_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr0, eta_min, t_max, b1, b2, (float)log((double)b1),
-                     (float)log((double)b2), eps, wd, state_in, state_out, max_grad_norm, nonfinite);
+                     (float)log((double)b2), eps, wd, state_in, state_out, max_grad_norm, nonfinite, gnorm_out);
   V4H_CHECK_LAUNCH("adamw_sched");
   return V4H_OK;
 }

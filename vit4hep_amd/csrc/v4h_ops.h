@@ -71,14 +71,15 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s);
 int silu_bwd(Mode m, const float* dsilu, const float* pre, void* out, int n, hipStream_t s);  // out = dsilu * silu'(pre)
 
 // ---- CFM step pieces ----
-int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per_sample, hipStream_t s);
-int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s);
+int cfm_prepare(const float* x1, const float* x0, const float* t, float* xt, float* target, int B, int per_sample, hipStream_t s, float* zero0 = nullptr,
+                float* zero1 = nullptr);  // zero0 / zero1: optional scalars set to 0 by the same launch
+int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, long n, hipStream_t s, bool zero_first = true);
 int sq_norm_accum(const float* g, long n, float* out, hipStream_t s);  // out[0] += sum g^2 (atomic)
 int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
                float bc1, float bc2, int* nonfinite, hipStream_t s);
 // the same with the step index and the cosine-schedule position on the device (state_in / state_out: 4 ints each, distinct)
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
-                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, hipStream_t s);
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s);
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
 int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
 

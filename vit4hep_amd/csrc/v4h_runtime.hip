@@ -926,6 +926,16 @@ extern "C" int32_t v4h_cfm_prepare(const float* x1, const float* x0, const float
   V4H_CHECK_ARG(x1 && x0 && t && xt && target && B > 0 && per > 0 && per < (1LL << 31), "cfm_prepare: bad argument");
   return cfm_prepare(x1, x0, t, xt, target, B, (int)per, (hipStream_t)s);
 }
+// the two above for an update loop without fill launches: the trajectory kernel also zeroes the step's scalar accumulators, the loss kernel adds into one
+extern "C" int32_t v4h_cfm_prepare_z(const float* x1, const float* x0, const float* t, float* xt, float* target, int32_t B, int64_t per, void* s, float* zero0,
+                                     float* zero1) {
+  V4H_CHECK_ARG(x1 && x0 && t && xt && target && B > 0 && per > 0 && per < (1LL << 31), "cfm_prepare_z: bad argument");
+  return cfm_prepare(x1, x0, t, xt, target, B, (int)per, (hipStream_t)s, zero0, zero1);
+}
+extern "C" int32_t v4h_mse_loss_acc(const float* v, const float* target, float* loss, float* dv, int64_t n, void* s) {
+  V4H_CHECK_ARG(v && target && loss && n > 0, "mse_loss_acc: bad argument");
+  return mse_fwd_bwd(v, target, loss, dv, n, (hipStream_t)s, false);
+}
 extern "C" int32_t v4h_mse_loss(const float* v, const float* target, float* loss, float* dv, int64_t n, void* s) {
   V4H_CHECK_ARG(v && target && loss && n > 0, "mse_loss: bad argument");
   return mse_fwd_bwd(v, target, loss, dv, n, (hipStream_t)s);
@@ -942,10 +952,11 @@ extern "C" int32_t v4h_adamw_step(float* p, const float* g, float* m, float* v, 
 }
 extern "C" int32_t v4h_adamw_step_sched(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr0, float eta_min,
                                         int32_t t_max, float b1, float b2, float eps, float wd, const int32_t* state_in, int32_t* state_out, float max_grad_norm,
-                                        void* s, int32_t* nonfinite) {
+                                        void* s, int32_t* nonfinite, float* gnorm_out) {
   V4H_CHECK_ARG(p && g && m && v && n > 0 && state_in && state_out && t_max > 0, "adamw_step_sched: bad argument");
   V4H_CHECK_ARG(state_in != state_out, "adamw_step_sched: d_state_in and d_state_out must be distinct (every thread reads the one, one thread writes the other)");
-  return adamw_step_sched(p, g, m, v, n, gnorm_sq, max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out, max_grad_norm, nonfinite, (hipStream_t)s);
+  return adamw_step_sched(p, g, m, v, n, gnorm_sq, max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out, max_grad_norm, nonfinite, gnorm_out,
+                          (hipStream_t)s);
 }
 extern "C" int32_t v4h_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n, void* s) {
   V4H_CHECK_ARG(out && a && b && n > 0, "axpby: bad argument");

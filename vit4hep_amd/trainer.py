@@ -105,8 +105,8 @@ class CFMTrainer:
         self.reducer = BucketReducer(self.flat_g, self.group)
         self.comm_reserve_cus = int(os.environ.get("V4H_COMM_RESERVE_CUS", "0"))  # multiple of 8 in [0, 64]
         self.stage_events = None
-        self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=dev)
-        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self._scal = torch.zeros(4, dtype=torch.float32, device=dev)  # loss | squared gradient norm | gradient norm of the step in progress
+        self.loss, self.gnorm_sq, self.gnorm = self._scal[0], self._scal[1], self._scal[2]
         self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
         self._t_ring, self._t_i = None, 0
         self.async_t = os.environ.get("V4H_ASYNC_T", "1") != "0"  # A/B hook: 0 = the reference's pageable .to(device) (a host sync per step)
@@ -183,10 +183,15 @@ class CFMTrainer:
         x0 = _lib.require_cuda(x0, "x0")
         s = _lib.stream_ptr(dev)
         xt, target = torch.empty_like(x), torch.empty_like(x)
-        _lib.check(lib.v4h_cfm_prepare(_lib.ptr(x), _lib.ptr(x0), _lib.ptr(t), _lib.ptr(xt), _lib.ptr(target), B, x[0].numel(), s), "v4h_cfm_prepare")
+        # the step's scalars - loss, squared gradient norm, gradient norm - in one fresh 16-byte tensor: zeroed by the trajectory kernel, accumulated into by
+        # the loss / norm kernels, the norm's root written by the update kernel: no fill, clone or sqrt launches (each 5 us of serial stream time)
+        self._scal = torch.empty(4, dtype=torch.float32, device=dev)
+        self.loss, self.gnorm_sq, self.gnorm = self._scal[0], self._scal[1], self._scal[2]
+        _lib.check(lib.v4h_cfm_prepare_z(_lib.ptr(x), _lib.ptr(x0), _lib.ptr(t), _lib.ptr(xt), _lib.ptr(target), B, x[0].numel(), s, _lib.ptr(self.loss),
+                                         _lib.ptr(self.gnorm_sq)), "v4h_cfm_prepare_z")
         v, ws = run_forward(self.net, self.p_views, xt, t, c, True, ws=self._ws, reuse_operands=self.prepare_ahead)
         dv = torch.empty_like(v)
-        _lib.check(lib.v4h_mse_loss(_lib.ptr(v), _lib.ptr(target), _lib.ptr(self.loss), _lib.ptr(dv), v.numel(), s), "v4h_mse_loss")
+        _lib.check(lib.v4h_mse_loss_acc(_lib.ptr(v), _lib.ptr(target), _lib.ptr(self.loss), _lib.ptr(dv), v.numel(), s), "v4h_mse_loss_acc")
         W = world()
         if W > 1:  # DDP averages gradients: fold 1/world into the seed, then SUM
             _lib.check(lib.v4h_axpby(_lib.ptr(dv), _lib.ptr(dv), _lib.ptr(dv), 1.0 / W, 0.0, dv.numel(), s), "v4h_axpby")
@@ -270,7 +275,6 @@ class CFMTrainer:
         lib = _lib.load()
         loss = self.loss_and_grads(x, c, t, x0)
         s = _lib.stream_ptr(self.flat_p.device)
-        self.gnorm_sq.zero_()
         _lib.check(lib.v4h_sq_norm_accum(_lib.ptr(self.flat_g), self.total, _lib.ptr(self.gnorm_sq), s), "v4h_sq_norm_accum")
         self.step_count += 1
         # `step > MIN_STEP_SKIP` of the reference is the 0-based index of the training loop (base_experiment.py:475-479,586)
@@ -281,7 +285,8 @@ class CFMTrainer:
         _lib.check(
             lib.v4h_adamw_step_sched(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
                                      _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations,
-                                     self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite)),
+                                     self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite),
+                                     _lib.ptr(self.gnorm)),
             "v4h_adamw_step_sched",
         )
         if capturing:  # a replayed graph has fixed pointers: copy the new counters back instead of swapping the two buffers
@@ -289,13 +294,13 @@ class CFMTrainer:
         else:
             self._cur ^= 1
         self.net.weights_epoch += 1  # parameters rewritten through raw pointers: invalidate cached operand copies (ViT.operands_current)
-        out_loss = loss.clone()
+        out_loss = loss  # (this step's own scalar tensor: nothing else writes it)
         if collectives_enabled():
             dist.all_reduce(out_loss, op=dist.ReduceOp.SUM, group=self.group)
             out_loss /= world()
         if not capturing and self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
             self.raise_if_nonfinite()
-        return out_loss, self.gnorm_sq.sqrt()
+        return out_loss, self.gnorm
 
     def raise_if_nonfinite(self):
         """Host look at the sticky device counter of skipped (non-finite) updates: raise like the reference.  The optimizer's step index and the LR
