@@ -501,6 +501,7 @@ def main():
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
     e1.record()
+    host_enqueue = time.perf_counter() - t0  # the host has issued every launch of the timed steps; what remains is the device's backlog
     sync()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
@@ -547,6 +548,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
+            "host_enqueue_frac": round(host_enqueue / wall, 3),  # < 1: the host runs ahead of the device (the step is not launch-bound)
         }
         rec["roofline"]["traffic_source"] = ("profiles/step_hbm_traffic.json (builder-measured PMC passes over this program, digest-matched to the kernel "
                                              "sources of this build; not measured in this run)")

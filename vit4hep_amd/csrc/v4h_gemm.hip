@@ -36,6 +36,26 @@ int g_kernel = kernel_from_env();
 // Contraction classes on the ring kernel under KERNEL_AUTO (bits: 1 forward plain store, 2 forward GELU of the update step - two outputs, 4 dgrad
 // plain store, 8 dgrad DGELU, 16 split-K weight-gradient slabs, 32 forward GELU without the saved derivative - inference), wherever the shape is eligible.
 int g_pp = env_flag("V4H_GEMM2_PP", 53) & 63;
+// Tile shape of the two N = mlp_hidden contractions with the fused GELU / GELU' epilogues (two-workgroup kernel, 512 workgroup slots on the chip).  All
+// tiles of a call take the same time and the persistent grid deals them out statically, so a call costs ceil(tiles / slots) ROUNDS: ds2's fc1 is 1620
+// tiles of 128 x 160 = 3.16 rounds paid as 4, but 2025 tiles of 128 x 128 = 3.96 rounds of tiles 0.8 times the size - +2.2 % on the whole step
+// (243.5 / 242.3 vs 238.3 / 237.0 steps/s, interleaved, same box; 96 x 160 and 128 x 96: 0 / -0.6 %).  -1 (default): per call, the shape with the
+// fewest rounds x tile area, smaller tiles charged a few per cent for their lower FLOP per staged byte.  V4H_MLP_TILE = 0 .. 3 pins 128 x 160, 128 x 128,
+// 96 x 160, 128 x 96 (A/B hook).
+int g_mlp_tile = env_flag("V4H_MLP_TILE", -1);
+inline int pick_mlp_tile(const GemmArgs& a) {
+  if (g_mlp_tile >= 0) return g_mlp_tile;
+  const long slots = 2L * v4h_compute_units();
+  auto cost = [&](int bi, int bj, double penalty) -> double {
+    const long tiles = (long)((a.I + bi - 1) / bi) * ((a.J + bj - 1) / bj);
+    return (double)((tiles + slots - 1) / slots) * bi * bj * penalty;
+  };
+  int best = 0;
+  double c = cost(128, 160, 1.0);
+  if (a.J % 128 == 0 && cost(128, 128, 1.04) < c) { best = 1; c = cost(128, 128, 1.04); }
+  if (cost(96, 160, 1.08) < c) { best = 2; c = cost(96, 160, 1.08); }
+  return best;
+}
 int g_small = env_flag("V4H_GEMM_SMALL", 1);  // A/B hook: 0 = the tiled kernel also for the batch-row contractions
 
 #ifdef V4H_ABLATIONS
@@ -94,7 +114,13 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
     case EPI_EMBED: return run<T, T, false, false, 128, 160, EPI_EMBED>(a, 1, s, "gemm_fwd/embed");
     case EPI_GATE_RESID: return run<T, T, false, false, 128, 160, EPI_GATE_RESID>(a, 1, s, "gemm_fwd/gate_resid");
     case EPI_GELU:
-      if constexpr (sizeof(T) == 2) return v4h_gemm_launch<GemmCfg<T, T, false, false, 128, 160, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu");
+      if constexpr (sizeof(T) == 2) {
+        const int mt = pick_mlp_tile(a);
+        if (mt == 1 && a.J % 128 == 0) return v4h_gemm_launch<GemmCfg<T, T, false, false, 128, 128, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu128");
+        if (mt == 2) return v4h_gemm_launch<GemmCfg<T, T, false, false, 96, 160, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu96");
+        if (mt == 3 && a.J % 96 == 0) return v4h_gemm_launch<GemmCfg<T, T, false, false, 128, 96, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu_96c");
+        return v4h_gemm_launch<GemmCfg<T, T, false, false, 128, 160, 64, 2, 2, EPI_GELU, false, 9>>(a, 1, s, "gemm_fwd/gelu");
+      }
       else return run<T, T, false, false, 128, 160, EPI_GELU>(a, 1, s, "gemm_fwd/gelu");
     case EPI_UNPATCH: return run<T, T, false, false, 128, 96, EPI_UNPATCH>(a, 1, s, "gemm_fwd/unpatch");
     case EPI_RELU: return run<T, T, false, false, 128, 160, EPI_RELU>(a, 1, s, "gemm_fwd/relu");
@@ -121,7 +147,13 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
       return run_store<T, true>(a, s, "gemm_dgrad/store");
     }
     case EPI_DGELU:
-      if constexpr (sizeof(T) == 2) return v4h_gemm_launch<GemmCfg<T, T, false, true, 128, 160, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu");
+      if constexpr (sizeof(T) == 2) {
+        const int mt = pick_mlp_tile(a);
+        if (mt == 1 && a.J % 128 == 0) return v4h_gemm_launch<GemmCfg<T, T, false, true, 128, 128, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu128");
+        if (mt == 2) return v4h_gemm_launch<GemmCfg<T, T, false, true, 96, 160, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu96");
+        if (mt == 3 && a.J % 96 == 0) return v4h_gemm_launch<GemmCfg<T, T, false, true, 128, 96, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu_96c");
+        return v4h_gemm_launch<GemmCfg<T, T, false, true, 128, 160, 64, 2, 2, EPI_DGELU, false, 9>>(a, 1, s, "gemm_dgrad/dgelu");
+      }
       else return run<T, T, false, true, 128, 160, EPI_DGELU>(a, 1, s, "gemm_dgrad/dgelu");
     case EPI_DSILU: return run<T, T, false, true, 128, 160, EPI_DSILU>(a, 1, s, "gemm_dgrad/dsilu");
     case EPI_ACCUM_F32: return run<T, T, false, true, 128, 160, EPI_ACCUM_F32>(a, 1, s, "gemm_dgrad/accum");
@@ -173,6 +205,8 @@ int gemm_wgrad_splitk(Mode m, int I, int J, int K) {
     const int tiles = ((I + 95) / 96) * ((J + 159) / 160);
     sk = tiles >= 40 ? 8 : 16;
     if (tiles < 8) sk = 32;
+    static const int small_sk = env_flag("V4H_WGRAD_SMALL_SPLITS", 0);  // A/B hook: K splits of the mid-sized weight gradients (attn.proj: 15 tiles)
+    if (small_sk > 0 && tiles >= 8 && tiles < 40) sk = small_sk;
   }
   const int maxk = K / 128;  // at least two K-steps of 64 per split
   if (sk > maxk) sk = maxk;
