@@ -328,7 +328,8 @@ def other_rates(mode, device):
     out = {}
     w = WORKLOADS["ds3"]
     model = build_model(w, mode, device)
-    tr = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
+    tr = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000,
+                    pipeline_update=os.environ.get("V4H_PIPELINE_UPDATE", "1") != "0")
     x, c = synthetic(w["shape"], w["B"], seed=3, device=device, cond=w["cond"])
     for _ in range(3):
         tr.step(x, c)
@@ -336,6 +337,7 @@ def other_rates(mode, device):
     t0 = time.perf_counter()
     for _ in range(10):
         _, gn = tr.step(x, c)
+    tr.finish()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     CFMTrainer.check_finite(gn)
@@ -478,7 +480,9 @@ def main():
     if dist.is_initialized():  # same initial weights everywhere, like DDP's constructor broadcast (base_experiment.py:163)
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
+    # pipeline_update: AdamW + operand casts on the library's side stream beside the next step's head (same arithmetic; V4H_PIPELINE_UPDATE=0: A/B hook)
+    pipelined = os.environ.get("V4H_PIPELINE_UPDATE", "1") != "0"
+    trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, pipeline_update=pipelined)
     x, c = synthetic(shape, B, seed=rank, device=device, cond=w["cond"])
     torch.manual_seed(1000 + rank)
 
@@ -500,6 +504,7 @@ def main():
         if step_marks is not None:
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
+    trainer.finish()  # (a pipelined update of the last step is ordered into the timed stream: both clocks below include it)
     e1.record()
     host_enqueue = time.perf_counter() - t0  # the host has issued every launch of the timed steps; what remains is the device's backlog
     sync()
@@ -540,7 +545,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.mode,
             "data": "synthetic",
-            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "update": "pipelined (AdamW + operand casts beside the next step's head)" if trainer.pipeline_update and world == 1 else "in line"},
             "details": {"tokens": T, "patch_dim": P, "depth": depth, "params": sum(p.numel() for p in model.parameters()),
                         "init": "random (xavier; zero-init tensors perturbed N(0,0.02))"},
             "loss": round(float(loss), 5),

@@ -105,6 +105,22 @@ int32_t v4h_vit_forward(const v4h_plan* plan, int32_t B, const void* const* d_pa
  * patch gather of reference models/base_model.py:209-215) instead of in front of it.  Nothing is skipped: the same kernels, another queue. */
 int32_t v4h_vit_prepare_operands(const v4h_plan* plan, int32_t B, const void* const* d_params, void* d_workspace, size_t workspace_bytes, int32_t training,
                                  void* stream, const float* d_pos);
+/* The optimizer update PIPELINED into the next step (the fused update loop of vit4hep_amd/trainer.py; reference experiments/base_experiment.py:573-597:
+ * clip_grad_norm_, AdamW, CosineAnnealingLR).  d_flat_p / g / m / v: one f32 buffer each holding every tensor of d_params at the element offsets
+ * `offsets[i]` (host array of v4h_plan_num_params() + 1 entries; d_params[i] == d_flat_p + offsets[i]; the gaps between tensors are updated too and must
+ * hold zeros).  The update of v4h_adamw_step_sched runs stage by stage in the order the next forward consumes the weights - embedders, every adaLN
+ * tensor and the final layer first, then block 0 ... depth-1 -, each stage followed by the operand copies of its tensors (as v4h_vit_prepare_operands),
+ * all on the plan's side stream behind what `stream` holds so far, with an event per stage.  The NEXT v4h_vit_forward on this workspace (training,
+ * V4H_FWD_REUSE_OPERANDS, same B) waits for a stage's event only in front of its first use of that stage's weights, so the 0.73 GB of AdamW traffic runs
+ * beside the next step's head and first blocks instead of between two steps; having waited for every stage, that forward leaves `stream` ordered behind
+ * the whole update.  Until then `stream` is NOT ordered behind it: call v4h_plan_join before parameters, moments or workspace are touched otherwise.
+ * (Any other forward on the plan joins first by itself.)  Same arithmetic as v4h_adamw_step_sched over the whole buffer: bit-identical results. */
+int32_t v4h_vit_update_ahead(const v4h_plan* plan, int32_t B, const void* const* d_params, float* d_flat_p, const float* d_flat_g, float* d_flat_m,
+                             float* d_flat_v, const int64_t* offsets, void* d_workspace, size_t workspace_bytes, const float* d_gnorm_sq, float max_norm,
+                             float lr0, float eta_min, int32_t t_max, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                             const int32_t* d_state_in, int32_t* d_state_out, int32_t* d_nonfinite, float* d_gnorm_out, void* stream, const float* d_pos);
+/* `stream` waits for everything the plan's side stream holds (a pipelined update, operand copies made ahead). */
+int32_t v4h_plan_join(const v4h_plan* plan, void* stream);
 /* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
  * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
  * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce

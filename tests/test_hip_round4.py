@@ -338,3 +338,66 @@ def test_whole_step_hipgraph_replays_the_update():
     tr2 = CFMTrainer(model2, iterations=3)
     tr2.load_state_dict(ck)
     assert tr2.sync_counters()["optimizer_steps"] == 8 and torch.equal(tr2.flat_m, tr.flat_m)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_pipelined_update_gives_the_in_line_trajectory(mode):
+    """pipeline_update: AdamW + operand casts staged on the side stream beside the next step's head (v4h_vit_update_ahead) - the same arithmetic per
+    element as the single in-line launch, so losses and weights follow the in-line run; the counters, the checkpoint and a mid-run batch-size change
+    (the update in flight was prepared for another workspace layout) behave."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(3)
+    x, c, noise = _data(cfg, 6, 43, 8)
+    runs = []
+    for pipe in (False, True):
+        model = U.build_models(cfg, mode, O.golden_fill(cfg))
+        tr = CFMTrainer(model, lr=3e-4, iterations=40, pipeline_update=pipe)
+        losses = []
+        for k, (t, x0) in enumerate(noise):
+            if k == 5:  # a smaller batch in the middle of the run
+                l, _ = tr.step(x[:4].contiguous(), c[:4].contiguous(), t[:4].contiguous(), x0[:4].contiguous())
+            else:
+                l, _ = tr.step(x, c, t, x0)
+            losses.append(float(l))
+        assert tr.sync_counters()["optimizer_steps"] == len(noise)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}  # (sync_counters joined the update in flight)
+        runs.append((losses, sd, tr.flat_m.clone()))
+    tol = 2e-6 if mode == "f32" else 2e-3
+    assert np.allclose(runs[0][0], runs[1][0], rtol=tol), (runs[0][0], runs[1][0])
+    for k, v in runs[0][1].items():
+        assert U.rel_err(runs[1][1][k], v) < (1e-3 if mode == "f32" else 5e-3), k
+    assert U.rel_err(runs[1][2], runs[0][2]) < (1e-3 if mode == "f32" else 2e-2)
+
+
+def test_pipelined_update_is_bit_identical_on_identical_gradients():
+    """One update from the same parameters, moments and gradients through both forms: every element bit for bit."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    x, c, noise = _data(cfg, 4, 45, 1)
+    t, x0 = noise[0]
+    outs = []
+    grads = None
+    for pipe in (False, True):
+        model = U.build_models(cfg, "f32", O.golden_fill(cfg))
+        tr = CFMTrainer(model, iterations=40, pipeline_update=pipe)
+        tr.step(x, c, t, x0)  # (builds workspace and moments)
+        tr.finish()
+        if grads is None:
+            grads = (tr.flat_g.clone(), tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone())
+        # second update on pinned inputs: overwrite state and gradient with the first run's, then apply the update alone through the trainer's own path
+        tr.flat_p.copy_(grads[1]); tr.flat_m.copy_(grads[2]); tr.flat_v.copy_(grads[3])
+        orig = tr.loss_and_grads
+
+        def fixed(*a, **k):
+            out = orig(*a, **k)
+            tr.flat_g.copy_(grads[0])
+            return out
+
+        tr.loss_and_grads = fixed
+        tr.step(x, c, t, x0)
+        tr.finish()
+        outs.append((tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

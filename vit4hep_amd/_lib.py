@@ -63,6 +63,9 @@ SIGNATURES = {
     "v4h_plan_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "v4h_vit_forward": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),
     "v4h_vit_prepare_operands": (_i32, [_vp, _i32, _pp, _vp, _sz, _i32, _vp, _vp]),
+    "v4h_vit_update_ahead": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64), _vp, _sz, _vp, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32, _f32,
+                                    _vp, _vp, _vp, _vp, _vp, _vp]),
+    "v4h_plan_join": (_i32, [_vp, _vp]),
     "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_backward_events": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _vp, _vp, _vp, _pp]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),

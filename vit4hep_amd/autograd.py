@@ -110,6 +110,29 @@ def prepare_operands(net, params, ws, B):
                                                     _lib.ptr(pos)), "v4h_vit_prepare_operands")
 
 
+@_on_device_of(2)
+def update_ahead(net, params, flat, offsets, ws, B, gnorm_sq, hyper, st_in, st_out, nonfinite, gnorm_out):
+    """The clip + AdamW update of the flat buffers ``flat = (p, g, m, v)`` pipelined into the next step (include/vit4hep_hip.h: v4h_vit_update_ahead):
+    staged on the plan's side stream, the next training forward on ``ws`` (``reuse_operands``) waits stage by stage.  ``offsets``: ctypes int64 array."""
+    plan = net._get_plan()
+    _, pos = net.device_tables(ws.device)
+    p, g, m, v = flat
+    _lib.check(
+        _lib.load().v4h_vit_update_ahead(plan.handle, int(B), _lib.pointer_table(params), _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), offsets, _lib.ptr(ws),
+                                         ws.numel(), _lib.ptr(gnorm_sq), *hyper, _lib.ptr(st_in), _lib.ptr(st_out), _lib.ptr(nonfinite), _lib.ptr(gnorm_out),
+                                         _lib.stream_ptr(ws.device), _lib.ptr(pos)),
+        "v4h_vit_update_ahead",
+    )
+
+
+def plan_join(net, device):
+    """The current stream of ``device`` waits for everything the plan's side stream holds (pipelined update, operand copies)."""
+    plan = net._plan
+    if plan is not None:
+        with _lib.on_device(torch.empty(0, device=device)):
+            _lib.check(_lib.load().v4h_plan_join(plan.handle, _lib.stream_ptr(device)), "v4h_plan_join")
+
+
 @_on_device_of(4)
 def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=None):
     plan = net._get_plan()

@@ -948,12 +948,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // that is skipped - non-finite norm, or gradient norm above max_grad_norm after MIN_STEP_SKIP iterations - advances neither, exactly as the reference's
 // early `return` skips optimizer.step() and scheduler.step(); the host never has to know.  state_in = {applied optimizer steps, scheduler steps,
 // updates skipped for max_grad_norm, -}; every thread reads state_in, thread 0 of workgroup 0 writes state_out (another 16 bytes: no race with readers).
-__global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+// The update runs over up to ADAM_MAX_RANGES element ranges of the flat buffers per launch (one range = the whole buffer, or the slices of one stage of
+// the pipelined update, v4h_vit_update_ahead); `leader` marks the ONE launch of a step that writes state_out and counts a skipped update.
+__global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const AdamRanges rg,
                                    const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float log_b1,
                                    float log_b2, float eps, float wd, const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm,
-                                   int* nonfinite, float* __restrict__ gnorm_out) {
+                                   int* nonfinite, float* __restrict__ gnorm_out, int leader) {
   const int applied = state_in[0], sched = state_in[1], skipped = state_in[2];
-  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  const bool lead = leader && blockIdx.x == 0 && threadIdx.x == 0;
   float coef = 1.0f;
   const float nrm = gnorm_sq ? sqrtf(*gnorm_sq) : 0.0f;
   if (lead && gnorm_out) *gnorm_out = nrm;  // the pre-clip norm clip_grad_norm_ returns (base_experiment.py:573-585), without a sqrt launch of its own
@@ -978,7 +980,11 @@ __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restric
   const float bc1 = -expm1f(stepf * log_b1), sqrt_bc2 = sqrtf(-expm1f(stepf * log_b2));
   const float lr = eta_min + (lr0 - eta_min) * 0.5f * (1.0f + cospif((float)sched / (float)t_max));
   if (gnorm_sq) coef = fminf(1.0f, clip / (nrm + 1e-6f));
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  int r = 0;
+  while (r + 1 < rg.count && (int)blockIdx.x >= rg.first_block[r + 1]) ++r;  // this workgroup's range (wave-uniform)
+  const long lo = rg.lo[r], hi = lo + rg.n[r];
+  const long nb = rg.first_block[r + 1] - rg.first_block[r];
+  for (long i = lo + (long)(blockIdx.x - rg.first_block[r]) * blockDim.x + threadIdx.x; i < hi; i += nb * blockDim.x) {
     const float gi = g[i] * coef;
     float pi = p[i] * (1.0f - lr * wd);
     const float mi = m[i] * b1 + (1.0f - b1) * gi;
@@ -1273,12 +1279,31 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
   V4H_CHECK_LAUNCH("adamw");
   return V4H_OK;
 }
-int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
-                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s) {
-  hipLaunchKernelGGL(adamw_sched_kernel, dim3(nblocks(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, clip, lr0, eta_min, t_max, b1, b2, (float)log((double)b1),
-                     (float)log((double)b2), eps, wd, state_in, state_out, max_grad_norm, nonfinite, gnorm_out);
+int adamw_step_ranges(float* p, const float* g, float* m, float* v, const long* lo, const long* n, int count, const AdamwHyper& h, const float* gnorm_sq,
+                      const int* state_in, int* state_out, int* nonfinite, float* gnorm_out, bool leader, hipStream_t s) {
+  V4H_CHECK_ARG(count >= 1 && count <= ADAM_MAX_RANGES, "adamw: %d ranges (1 .. %d per launch)", count, ADAM_MAX_RANGES);
+  AdamRanges rg;
+  long total = 0;
+  for (int r = 0; r < count; ++r) total += n[r];
+  const int grid = nblocks(total, 1024);  // workgroups dealt to the ranges in proportion to their length, at least one each
+  int used = 0;
+  for (int r = 0; r < count; ++r) {
+    rg.lo[r] = lo[r]; rg.n[r] = n[r]; rg.first_block[r] = used;
+    int nb = (int)((double)grid * (double)n[r] / (double)(total > 0 ? total : 1) + 0.5);
+    used += nb < 1 ? 1 : nb;
+  }
+  rg.first_block[count] = used;
+  rg.count = count;
+  hipLaunchKernelGGL(adamw_sched_kernel, dim3(used), dim3(256), 0, s, p, g, m, v, rg, gnorm_sq, h.clip, h.lr0, h.eta_min, h.t_max, h.b1, h.b2, (float)log((double)h.b1),
+                     (float)log((double)h.b2), h.eps, h.wd, state_in, state_out, h.max_grad_norm, nonfinite, gnorm_out, leader ? 1 : 0);
   V4H_CHECK_LAUNCH("adamw_sched");
   return V4H_OK;
+}
+int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s) {
+  const long lo = 0;
+  const AdamwHyper h{clip, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm};
+  return adamw_step_ranges(p, g, m, v, &lo, &n, 1, h, gnorm_sq, state_in, state_out, nonfinite, gnorm_out, true, s);
 }
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s) {
   V4H_CHECK_ARG(n % 4 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)slab % 16) == 0, "slab_reduce: size / alignment");

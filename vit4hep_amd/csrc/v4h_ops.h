@@ -77,6 +77,12 @@ int mse_fwd_bwd(const float* v, const float* target, float* loss, float* dv, lon
 int sq_norm_accum(const float* g, long n, float* out, hipStream_t s);  // out[0] += sum g^2 (atomic)
 int adamw_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr, float b1, float b2, float eps, float wd,
                float bc1, float bc2, int* nonfinite, hipStream_t s);
+constexpr int ADAM_MAX_RANGES = 12;
+struct AdamRanges { long lo[ADAM_MAX_RANGES], n[ADAM_MAX_RANGES]; int first_block[ADAM_MAX_RANGES + 1]; int count; };
+struct AdamwHyper { float clip, lr0, eta_min; int t_max; float b1, b2, eps, wd, max_grad_norm; };
+// over `count` element ranges [lo, lo + n) of the flat buffers in one launch; leader: the launch of a step that writes state_out / counts a skip
+int adamw_step_ranges(float* p, const float* g, float* m, float* v, const long* lo, const long* n, int count, const AdamwHyper& h, const float* gnorm_sq,
+                      const int* state_in, int* state_out, int* nonfinite, float* gnorm_out, bool leader, hipStream_t s);
 // the same with the step index and the cosine-schedule position on the device (state_in / state_out: 4 ints each, distinct)
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
                      float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s);

@@ -58,6 +58,8 @@ struct v4h_plan {
   mutable hipEvent_t evOps = nullptr;   // operand copies made ahead of the next forward on the side stream (v4h_vit_prepare_operands)
   mutable bool ops_pending = false;     // ... and not yet waited for by a forward
   mutable unsigned mark_live = 0;       // side-stream marks recorded by the backward call in progress
+  mutable std::vector<hipEvent_t> evUp; // pipelined update (v4h_vit_update_ahead): one event per stage, in the order the forward consumes the weights
+  mutable unsigned long long upd_mask = 0;  // stages whose event the next forward still has to wait for
   mutable int evi = 0;
   mutable bool side_ok = false;
   mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
@@ -229,6 +231,7 @@ extern "C" void v4h_plan_destroy(v4h_plan* p) {
     for (int i = 0; i < 8; ++i) hipEventDestroy(p->ev[i]);
     for (int i = 0; i < 4; ++i) hipEventDestroy(p->evS[i]);
     hipEventDestroy(p->evOps);
+    for (hipEvent_t e : p->evUp) hipEventDestroy(e);
     hipStreamDestroy(p->side);
   }
   delete p;
@@ -464,12 +467,20 @@ static int check_common(const v4h_plan* p, int B, const void* const* params, voi
 }
 
 // operand copies of the weights: cast to the mode type, awkward extents zero-padded, adaLN weights / biases concatenated (layout())
-static void operand_items(const Ctx& c, std::vector<CastPadItem>& items) {
+// stage of the pipelined update a parameter belongs to: 0 = everything the head of the forward needs (embedders, EVERY adaLN tensor - the modulation
+// table of all blocks is one contraction at the head -, the final layer, fine-tuning mappers), 1 + i = the four Linears of block i
+static int update_stage_of(const v4h_plan& p, int i) {
+  if (i < P_BLOCK0 || i >= p.fin(0)) return 0;
+  const int k = (i - P_BLOCK0) % B_COUNT;
+  return k >= B_ADAW ? 0 : 1 + (i - P_BLOCK0) / B_COUNT;
+}
+static void operand_items(const Ctx& c, std::vector<CastPadItem>& items, int stage = -1) {  // stage -1: all
   const v4h_plan* p = &c.p;
   const WS& w = c.w;
   const int D = p->D;
   for (int i = 0; i < p->nparams(); ++i) {
     if (!w.wop[i]) continue;
+    if (stage >= 0 && update_stage_of(*p, i) != stage) continue;
     int rp = p->rows[i], cp = p->cols[i];
     if (i == P_XW) cp = p->Pxpad;
     if (p->mapper() && i == p->xmw()) { rp = p->Pxpad; cp = p->Ppad; }
@@ -478,6 +489,7 @@ static void operand_items(const Ctx& c, std::vector<CastPadItem>& items) {
     if (i == p->fin(F_LINW)) rp = p->Ppad;
     items.push_back(CastPadItem{c.pf(i), w.wop[i], p->rows[i], p->cols[i], rp, cp, 0});
   }
+  if (stage > 0) return;
   items.push_back(CastPadItem{c.pf(p->fin(F_LINB)), w.linb_pad, 1, p->P, 1, p->Ppad, 1});
   for (int i = 0; i <= p->depth; ++i) {  // concatenated adaLN biases
     const bool last = i == p->depth;
@@ -513,6 +525,77 @@ extern "C" int32_t v4h_vit_prepare_operands(const v4h_plan* p, int32_t B, const 
     if (hipEventRecord(p->evOps, st) != hipSuccess) { v4h_set_error("vit_prepare_operands: cannot record"); return V4H_ERR_HIP; }
     p->ops_pending = true;
   }
+  return V4H_OK;
+}
+
+// The optimizer update PIPELINED into the next step.  clip + AdamW over the flat parameter / gradient / moment buffers, stage by stage in the order the
+// next forward consumes the weights, each stage followed by the operand copies of its tensors, all on the plan's side stream behind what `stream` holds
+// so far (the gradient norm); an event per stage.  The next training forward on this workspace (V4H_FWD_REUSE_OPERANDS) waits for a stage's event only in
+// front of its first use of that stage's weights: the 0.73 GB of AdamW traffic and the casts run beside the next step's head and first blocks - a
+// bandwidth-bound kernel beside launch-latency-bound and matrix-bound ones - instead of between two steps.  `stream` is NOT ordered behind the update.
+extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void* const* params, float* flat_p, const float* flat_g, float* flat_m, float* flat_v,
+                                        const int64_t* offsets, void* ws, size_t ws_bytes, const float* gnorm_sq, float max_norm, float lr0, float eta_min,
+                                        int32_t t_max, float b1, float b2, float eps, float wd, float max_grad_norm, const int32_t* state_in, int32_t* state_out,
+                                        int32_t* nonfinite, float* gnorm_out, void* stream, const float* pos) {
+  RUN(check_common(p, B, params, ws, ws_bytes, true, "vit_update_ahead"));
+  V4H_CHECK_ARG(flat_p && flat_g && flat_m && flat_v && offsets && state_in && state_out && state_in != state_out && t_max > 0, "vit_update_ahead: bad argument");
+  V4H_CHECK_ARG(!p->mapper() && !p->cmapper(), "vit_update_ahead: networks with a fine-tuning mapper are updated by the caller's own optimizer");
+  V4H_CHECK_ARG(!p->mapped || pos != nullptr, "vit_update_ahead: a plan made by v4h_plan_create_mapped needs d_pos");
+  V4H_CHECK_ARG(p->depth + 1 <= 63, "vit_update_ahead: depth %d", p->depth);
+  for (int i = 0; i < p->nparams(); ++i) {
+    V4H_CHECK_ARG(params[i] == (const void*)(flat_p + offsets[i]), "vit_update_ahead: parameter %d is not the slice of the flat buffer its offset names", i);
+    V4H_CHECK_ARG(offsets[i + 1] >= offsets[i] + (int64_t)p->rows[i] * (p->cols[i] ? p->cols[i] : 1), "vit_update_ahead: offsets of parameter %d overlap the next", i);
+  }
+  Ctx c{*p, B, params, WS(), (hipStream_t)stream};
+  layout(*p, B, true, (char*)ws, c.w);
+  RUN(side_init(*p));
+  while ((int)p->evUp.size() < p->depth + 1) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
+    p->evUp.push_back(e);
+  }
+  hipStream_t st = c.s;
+  if (g_overlap_wgrad) {
+    RUN(side_wait_main(*p, c.s));
+    st = p->side;
+  }
+  const AdamwHyper h{max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm};
+  for (int stage = 0; stage <= p->depth; ++stage) {
+    std::vector<long> lo, n;
+    auto range = [&](int i0, int i1) { lo.push_back((long)offsets[i0]); n.push_back((long)(offsets[i1] - offsets[i0])); };
+    if (stage == 0) {
+      range(0, P_BLOCK0);
+      for (int i = 0; i < p->depth; ++i) range(p->blk(i, B_ADAW), p->blk(i, B_ADAW) + 2);
+      range(p->fin(0), p->nparams());
+    } else {
+      range(p->blk(stage - 1, 0), p->blk(stage - 1, B_ADAW));
+    }
+    for (size_t r0 = 0; r0 < lo.size(); r0 += ADAM_MAX_RANGES) {
+      const int cnt = (int)std::min<size_t>(ADAM_MAX_RANGES, lo.size() - r0);
+      RUN(adamw_step_ranges(flat_p, flat_g, flat_m, flat_v, lo.data() + r0, n.data() + r0, cnt, h, gnorm_sq, state_in, state_out, nonfinite, gnorm_out,
+                            stage == 0 && r0 == 0, st));
+    }
+    std::vector<CastPadItem> items;
+    operand_items(c, items, stage);
+    if (!items.empty()) RUN(cast_pad_many(p->mode, items.data(), (int)items.size(), st));
+    if (stage == 0) {
+      if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, c.w.pe, p->T, p->D, st));
+      else RUN(pos_embed_fwd(c.pf(P_FREQS), c.w.pe, p->pg, p->D, st));
+    }
+    if (g_overlap_wgrad && hipEventRecord(p->evUp[stage], st) != hipSuccess) { v4h_set_error("vit_update_ahead: cannot record"); return V4H_ERR_HIP; }
+  }
+  p->upd_mask = g_overlap_wgrad ? ((1ull << (p->depth + 1)) - 1) : 0;
+  return V4H_OK;
+}
+// `stream` waits for everything the plan's side stream holds (a pipelined update, operand copies made ahead): call before the parameters, the moments or
+// the workspace are touched from `stream` by anything but the next v4h_vit_forward.
+extern "C" int32_t v4h_plan_join(const v4h_plan* p, void* stream) {
+  V4H_CHECK_ARG(p != nullptr, "plan_join: null plan");
+  if (!p->side_ok) return V4H_OK;
+  RUN(side_init(*p));
+  RUN(main_wait_side(*p, (hipStream_t)stream));
+  p->upd_mask = 0;
+  p->ops_pending = false;
   return V4H_OK;
 }
 
@@ -552,7 +635,18 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // whole conditioning chain on the side stream, joined before the first block - left the main stream idle for 80 us per forward.
   // (A third queue for the t_embedder was worth +0.3-0.9 % on one rank and serialised the whole pass as soon as a process group's communication
   // stream existed - 126 instead of 216 steps/s - and was removed in round 3.)
-  const bool fork = g_overlap_wgrad && !same_c;
+  if (p->upd_mask && !(reuse && training)) {  // a pipelined update is in flight and this is not the forward it was made for: simply join
+    RUN(main_wait_side(*p, c.s));
+    p->upd_mask = 0;
+  }
+  auto wait_update = [&](int stage) -> int {  // the weights of `stage` are about to be read: their AdamW + operand copies on the side stream must be done
+    if (p->upd_mask & (1ull << stage)) {
+      if (hipStreamWaitEvent(c.s, p->evUp[stage], 0) != hipSuccess) { v4h_set_error("vit_forward: cannot wait for the update of stage %d", stage); return V4H_ERR_HIP; }
+      p->upd_mask &= ~(1ull << stage);
+    }
+    return V4H_OK;
+  };
+  const bool fork = g_overlap_wgrad && !same_c && !p->upd_mask;  // (behind a pipelined update the side stream is busy: the c_embedder stays on the main stream)
   hipStream_t cs = c.s;  // stream of the c_embedder
   if (fork) {
     RUN(side_wait_main(*p, c.s));
@@ -566,6 +660,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     if (hipStreamWaitEvent(c.s, p->evOps, 0) != hipSuccess) { v4h_set_error("vit_forward: cannot wait for the operand copies"); return V4H_ERR_HIP; }
     p->ops_pending = false;
   }
+  RUN(wait_update(0));
   if (p->mapper()) {  // fine-tuning embedding mapper: xp = silu(patches Wm^T + bm)   (experiment_finetuning.py:80-91)
     GemmArgs a = gargs(w.xpm, p->Ppad, c.W(p->xmw()), p->Ppad, BT, p->Pxpad, p->Ppad);
     a.e.out = w.xp; a.e.ldo = p->Pxpad; a.e.out2 = training ? w.xpre : nullptr; a.e.ldo2 = p->Pxpad; a.e.bias = (const float*)w.xmb_pad;
@@ -626,6 +721,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   for (int i = 0; i < p->depth; ++i) {
     const BlockWS& b = w.blk[i];
     const float* mod = w.mod[i];
+    RUN(wait_update(1 + i));
     // Gated residual updates (nn/vit.py:331-332).  Fused form (default): the branch contractions store y = branch output with a plain epilogue
     // and the NEXT LayerNorm kernel applies x += gate * y while it reads the row anyway - the f32 residual stream is then read and written once per
     // branch by a streaming kernel instead of by a contraction epilogue (16 us per call there, 8 here).  V4H_LN_RESID=0: the GATE_RESID epilogue.

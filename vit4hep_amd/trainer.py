@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .autograd import prepare_operands, run_backward, run_backward_events, run_forward
+from .autograd import plan_join, prepare_operands, run_backward, run_backward_events, run_forward, update_ahead
 from .parallel import BucketReducer, collectives_enabled, world
 
 
@@ -39,7 +39,7 @@ class CFMTrainer:
     MIN_STEP_SKIP = 1000  # base_experiment.py:31
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None,
-                 nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0):
+                 nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0, pipeline_update=None):
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
 
         self.model = model
@@ -60,6 +60,13 @@ class CFMTrainer:
         self.step_count = 0  # host's count of applied updates; the device's own counters (self._state) are what the arithmetic uses
         self.iteration = 0   # `step` of the reference's training loop: every call of step(), applied or skipped
         self.group = group
+        # Pipelined update (opt-in; V4H_PIPELINE_UPDATE=1 or pipeline_update=True): AdamW + the operand copies of the new weights run on the library's
+        # side stream, stage by stage in the order the next forward needs them, BESIDE the next step's head and first blocks (the same arithmetic, bit
+        # for bit; include/vit4hep_hip.h: v4h_vit_update_ahead).  step() then returns before the update has been ordered into the current stream:
+        # everything of this class that reads parameters or moments joins first (finish()), and so must a caller that touches them with its own ops
+        # between two steps.  Single rank, no CUDA-graph capture, no embedding mappers.
+        self.pipeline_update = (os.environ.get("V4H_PIPELINE_UPDATE") == "1") if pipeline_update is None else bool(pipeline_update)
+        self._ahead = None  # (workspace pointer, batch) the operand copies of the update in flight were made for
         # The reference raises on a non-finite gradient norm BEFORE optimizer.step(), also without clipping (max_norm = inf; base_experiment.py:573-585).
         # Here the update kernel skips such a step on the device and bumps a sticky counter - and while that counter is non-zero it skips (and counts)
         # EVERY later update too, so no update is ever applied with a shifted Adam / LR-schedule index.  The host looks at the counter every
@@ -102,6 +109,8 @@ class CFMTrainer:
             i = depth - 1 - j
             self.stage_slices.append(bounds(blk0 + 10 * i, blk0 + 10 * (i + 1)))
         self.stage_slices.append(bounds(0, blk0))
+        self._offsets_c = (_lib.C.c_int64 * (len(params) + 1))(*self.offsets, self.total)
+        self._last_B = None
         self.reducer = BucketReducer(self.flat_g, self.group)
         self.comm_reserve_cus = int(os.environ.get("V4H_COMM_RESERVE_CUS", "0"))  # multiple of 8 in [0, 64]
         self.stage_events = None
@@ -125,6 +134,8 @@ class CFMTrainer:
         self._cur = 0
 
     def _check_alias(self):
+        if self._ahead is not None and any(p.data_ptr() != v.data_ptr() for p, v in ((self.params[0], self.p_views[0]), (self.params[-1], self.p_views[-1]))):
+            self.finish()
         if any(p.data_ptr() != v.data_ptr() for p, v in ((self.params[0], self.p_views[0]), (self.params[-1], self.p_views[-1]))):
             m, v = self.flat_m, self.flat_v
             self._flatten()  # parameters were re-allocated (e.g. model.to(...)): adopt the new storage, keep the optimizer state (and the counters)
@@ -169,10 +180,15 @@ class CFMTrainer:
         x = _lib.require_cuda(x, "x")
         c = _lib.require_cuda(c, "c")
         B = x.shape[0]
+        self._last_B = B
         need = self.net._get_plan().workspace_bytes(B, True)
         if self._ws is None or self._ws.numel() != need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        if self.prepare_ahead:
+        ahead = self._ahead is not None and self._ahead == (self._ws.data_ptr(), B)
+        if self._ahead is not None and not ahead:
+            self.finish()  # (another batch size or workspace than the update in flight prepared for)
+        self._ahead = None
+        if self.prepare_ahead and not ahead:
             prepare_operands(self.net, self.p_views, self._ws, B)
         if t is None:  # reference: CPU generator for t, device generator for x_0 (models/base_model.py:209-212)
             t_host = self.model.time_distribution.sample([B] + [1] * (x.dim() - 1))
@@ -189,7 +205,7 @@ class CFMTrainer:
         self.loss, self.gnorm_sq, self.gnorm = self._scal[0], self._scal[1], self._scal[2]
         _lib.check(lib.v4h_cfm_prepare_z(_lib.ptr(x), _lib.ptr(x0), _lib.ptr(t), _lib.ptr(xt), _lib.ptr(target), B, x[0].numel(), s, _lib.ptr(self.loss),
                                          _lib.ptr(self.gnorm_sq)), "v4h_cfm_prepare_z")
-        v, ws = run_forward(self.net, self.p_views, xt, t, c, True, ws=self._ws, reuse_operands=self.prepare_ahead)
+        v, ws = run_forward(self.net, self.p_views, xt, t, c, True, ws=self._ws, reuse_operands=self.prepare_ahead or ahead)
         dv = torch.empty_like(v)
         _lib.check(lib.v4h_mse_loss_acc(_lib.ptr(v), _lib.ptr(target), _lib.ptr(self.loss), _lib.ptr(dv), v.numel(), s), "v4h_mse_loss_acc")
         W = world()
@@ -282,6 +298,18 @@ class CFMTrainer:
         self.iteration += 1
         st_in, st_out = self._state[self._cur], self._state[self._cur ^ 1]
         capturing = getattr(self, "_in_capture", False)
+        if self.pipeline_update and not capturing and not collectives_enabled() and self._ws is not None and self._last_B is not None:
+            hyper = (self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations, self.betas[0], self.betas[1], self.eps, self.wd,
+                     skip_above)
+            update_ahead(self.net, self.p_views, (self.flat_p, self.flat_g, self.flat_m, self.flat_v), self._offsets_c, self._ws, self._last_B, self.gnorm_sq,
+                         hyper, st_in, st_out, self.nonfinite, self.gnorm)
+            self._ahead = (self._ws.data_ptr(), self._last_B)
+            self._cur ^= 1
+            self.net.weights_epoch += 1
+            out_loss = loss
+            if self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
+                self.raise_if_nonfinite()
+            return out_loss, self.gnorm
         _lib.check(
             lib.v4h_adamw_step_sched(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
                                      _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations,
@@ -302,9 +330,17 @@ class CFMTrainer:
             self.raise_if_nonfinite()
         return out_loss, self.gnorm
 
+    def finish(self):
+        """Order a pipelined update (pipeline_update) into the current stream: call before parameters, moments or gradients are read by anything but the
+        next step().  A no-op otherwise."""
+        if self._ahead is not None:
+            plan_join(self.net, self.flat_p.device)
+            self._ahead = None
+
     def raise_if_nonfinite(self):
         """Host look at the sticky device counter of skipped (non-finite) updates: raise like the reference.  The optimizer's step index and the LR
         schedule live on the device and never advanced for a skipped update; the host's ``step_count`` is re-read from there."""
+        self.finish()
         skipped = int(self.nonfinite.item())
         self.sync_counters()
         if skipped:
@@ -313,6 +349,7 @@ class CFMTrainer:
 
     def sync_counters(self):
         """One 16-byte read: {applied optimizer steps, scheduler steps, updates skipped for max_grad_norm}; brings ``step_count`` in line."""
+        self.finish()
         a, k, skipped, _ = (int(v) for v in self._state[self._cur].tolist())
         self.step_count = a
         return {"optimizer_steps": a, "scheduler_steps": k, "skipped_max_grad_norm": skipped}
@@ -365,6 +402,7 @@ class CFMTrainer:
     def load_state_dict(self, sd):
         """Continue from ``state_dict()`` / ``checkpoint()`` of this class, or from the "optimizer" / "scheduler" entries written by the reference's
         torch.optim.AdamW + CosineAnnealingLR (a "model" entry, when present, is loaded into the model first)."""
+        self.finish()
         self._check_alias()
         if "model" in sd and sd["model"] is not None:
             self.model.load_state_dict(sd["model"])  # in place: the parameters stay views of the flat buffer
