@@ -365,8 +365,13 @@ def test_pipelined_update_gives_the_in_line_trajectory(mode):
         runs.append((losses, sd, tr.flat_m.clone()))
     tol = 2e-6 if mode == "f32" else 2e-3
     assert np.allclose(runs[0][0], runs[1][0], rtol=tol), (runs[0][0], runs[1][0])
+    D = cfg.hidden_dim
     for k, v in runs[0][1].items():
-        assert U.rel_err(runs[1][1][k], v) < (1e-3 if mode == "f32" else 5e-3), k
+        got = runs[1][1][k]
+        if k.endswith("attn.qkv.bias"):  # the key third has an analytically zero gradient: Adam-normalised rounding noise on both sides
+            keep = torch.cat([torch.arange(0, D), torch.arange(2 * D, 3 * D)]).to(v.device)
+            got, v = got[keep], v[keep]
+        assert U.rel_err(got, v) < (1e-3 if mode == "f32" else 5e-3), k
     assert U.rel_err(runs[1][2], runs[0][2]) < (1e-3 if mode == "f32" else 2e-2)
 
 

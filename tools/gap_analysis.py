@@ -9,7 +9,7 @@ f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
 # steady-state window: from the (skip)-th adamw kernel to the last one
-adam = [i for i, r in enumerate(rows) if "adamw" in r[2]]
+adam = [i for i, r in enumerate(rows) if "sq_norm_kernel" in r[2]]  # one per update step (the update itself may be several staged launches)
 lo, hi = adam[skip - 1] + 1, adam[-1] + 1
 win = rows[lo:hi]
 nsteps = len(adam) - skip

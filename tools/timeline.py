@@ -6,7 +6,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "adamw" in r[3]]
+adam = [i for i, r in enumerate(rows) if "sq_norm_kernel" in r[3]]  # one per update step (the update itself may be several staged launches)
 lo, hi = adam[-back - 1] + 1, adam[-back] + 1
 t0 = rows[lo][0]
 queues = sorted({r[2] for r in rows[lo:hi]})

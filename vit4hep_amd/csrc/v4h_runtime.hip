@@ -555,7 +555,9 @@ extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void
     p->evUp.push_back(e);
   }
   hipStream_t st = c.s;
-  if (g_overlap_wgrad) {
+  static const bool on_main = getenv("V4H_UPD_ON_MAIN") && getenv("V4H_UPD_ON_MAIN")[0] == '1';  // diagnostic: the staged update in line
+  const bool side = g_overlap_wgrad && !on_main;
+  if (side) {
     RUN(side_wait_main(*p, c.s));
     st = p->side;
   }
@@ -582,9 +584,9 @@ extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void
       if (pos) RUN(pos_embed_fwd_pos(c.pf(P_FREQS), pos, c.w.pe, p->T, p->D, st));
       else RUN(pos_embed_fwd(c.pf(P_FREQS), c.w.pe, p->pg, p->D, st));
     }
-    if (g_overlap_wgrad && hipEventRecord(p->evUp[stage], st) != hipSuccess) { v4h_set_error("vit_update_ahead: cannot record"); return V4H_ERR_HIP; }
+    if (side && hipEventRecord(p->evUp[stage], st) != hipSuccess) { v4h_set_error("vit_update_ahead: cannot record"); return V4H_ERR_HIP; }
   }
-  p->upd_mask = g_overlap_wgrad ? ((1ull << (p->depth + 1)) - 1) : 0;
+  p->upd_mask = side ? ((1ull << (p->depth + 1)) - 1) : 0;
   return V4H_OK;
 }
 // `stream` waits for everything the plan's side stream holds (a pipelined update, operand copies made ahead): call before the parameters, the moments or

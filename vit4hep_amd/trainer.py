@@ -118,7 +118,11 @@ class CFMTrainer:
         self.loss, self.gnorm_sq, self.gnorm = self._scal[0], self._scal[1], self._scal[2]
         self.nonfinite = torch.zeros((), dtype=torch.int32, device=dev)
         self._t_ring, self._t_i = None, 0
-        self.async_t = os.environ.get("V4H_ASYNC_T", "1") != "0"  # A/B hook: 0 = the reference's pageable .to(device) (a host sync per step)
+        # V4H_ASYNC_T=1: t through a ring of pinned buffers (_stage_t) instead of the reference's pageable .to(device).  Measured and left OFF: the
+        # steady-state step is the same (4.19 ms either way - the device, not the host, sets the pace), and once the host runs several steps ahead of
+        # the device for the first time the runtime stalls ONCE for 18-35 ms (growing its signal / kernel-argument pools) - at an unpredictable step,
+        # i.e. possibly inside a short timed region (profiles/r04_notes.md).  The pageable copy is the natural throttle that keeps the host one step ahead.
+        self.async_t = os.environ.get("V4H_ASYNC_T", "0") == "1"
         self.use_graph = os.environ.get("V4H_STEP_GRAPH") == "1"
         self._graph, self._graph_warm, self._in_capture = None, 0, False
         self._ws = None  # one training workspace kept across steps (2.6 GB at ds2 bs 128)
