@@ -828,6 +828,9 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
   const int ntiles = (Tn + 15) / 16;
   if constexpr (sizeof(T) == 2) {
     static const bool fused = !(getenv("V4H_ATTN_BWD_FUSED") && getenv("V4H_ATTN_BWD_FUSED")[0] == '0');
+    // (Round 4: the same kernel with 2 or 3 lane-side tiles per wave - 5 / 3 waves instead of 9, every streamed LDS fragment feeding 2 / 3 MFMAs, results bit-identical -
+    //  measured 61.6 / 72.5 us per call against 54.8 cold, 242 / 239 against 243-246 steps/s: this kernel wants MORE resident waves, not fewer LDS reads.
+    //  Kept out of the library: tools/experiments/attn_bwd_tpw.inc, profiles/r04_notes.md.)
     if (fused && Tn <= KC && ntiles <= 9) {  // single chunk: dQ, dK, dV of an item in one persistent, double-buffered kernel
       constexpr int NW = 9;
       const size_t lds = 4 * (size_t)AttnDense<T, 80>::BYTES + 2 * KC * sizeof(float);
