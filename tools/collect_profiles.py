@@ -3,12 +3,13 @@ usage: python tools/collect_profiles.py <tag> [round prefix, default r03]"""
 import json, os, shutil, sys
 
 tag = sys.argv[1]
-rp = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rp = sys.argv[2] if len(sys.argv) > 2 else "r04"
 R = f"gpurun_out/refresh_{tag}"
 for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"), ("step_timeline.txt", f"{rp}_step_timeline.txt"),
                  ("step_pmc_counters.md", f"{rp}_step_pmc_counters.md"), ("step_hbm_traffic.json", "step_hbm_traffic.json"), ("bench_final_bf16.json", f"{rp}_bench_final_bf16.json"),
                  ("ab_in_context.txt", f"{rp}_ab_in_context_{tag}.txt"), ("ds3_step_serialized.md", f"{rp}_ds3_step_serialized.md"),
-                 ("block_gemm_bench.txt", f"{rp}_block_gemm_bench.txt"), ("attn_bench.txt", f"{rp}_attn_bench.txt")):
+                 ("block_gemm_bench.txt", f"{rp}_block_gemm_bench.txt"), ("attn_bench.txt", f"{rp}_attn_bench.txt"), ("ddp_route.txt", f"{rp}_ddp_route_rehearsal.txt"),
+                 ("comm_interference.txt", f"{rp}_comm_interference_raw.txt")):
     if os.path.exists(f"{R}/{src}"):
         shutil.copy(f"{R}/{src}", f"profiles/{dst}")
 if os.path.exists(f"{R}/step_pmc_counters.md") and os.path.exists("tools/pmc_counters_header.md"):  # the audit's reading in front of the raw tables
@@ -16,8 +17,11 @@ if os.path.exists(f"{R}/step_pmc_counters.md") and os.path.exists("tools/pmc_cou
 if os.path.exists(f"{R}/ab_in_context.txt"):
     open(f"profiles/{rp}_ab_in_context_{tag}.txt", "w").write(
         "# In-context A/B of the switches the library keeps (tools/refresh_profiles.sh, part 3): two interleaved rounds on one box, each line one full `bench.py` run\n"
-        "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default (automatic choice); 0 / 8 = two-workgroup / ring kernel everywhere; V4H_GEMM2_PP = which\n"
-        "# contraction classes take the ring kernel (default 53); the rest switch one round-3 / round-2 lever off.\n" + open(f"{R}/ab_in_context.txt").read())
+        "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default build.  Round-4 levers switched off one at a time: V4H_MLP_TILE=0 (GELU / DGELU contractions\n"
+        "# on 128 x 160 tiles again), V4H_LNB_V2=0 (round-2 LayerNorm backward), V4H_PREPARE_AHEAD=0 (operand casts inside the forward); round-4 options measured neutral and left\n"
+        "# off: V4H_LNF_V2=1, V4H_PIPELINE_UPDATE=1, V4H_ASYNC_T=1 (the last costs a one-time 18-35 ms runtime stall when the host first runs ahead - it lands in these 40 steps);\n"
+        "# then the older switches: 0 / 8 = two-workgroup / ring kernel everywhere, whole-K kernels off, round-2 attention, 4 K-splits, per-block adaLN, no weight-gradient stream.\n"
+        + open(f"{R}/ab_in_context.txt").read())
 if os.path.exists(f"{R}/gemm2_ablation.txt"):
     old = open(f"profiles/{rp}_gemm2_ablation.txt").read() if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""
     hdr = old.split("\n\n")[0] + "\n\n" if old.startswith("#") else ""  # (keep a hand-written header, never an old body)

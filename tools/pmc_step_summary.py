@@ -15,7 +15,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 steps = int(sys.argv[1])
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 BASE = "gpurun_out/pmc_step"
 
 
@@ -88,6 +88,10 @@ BT, D, M = 17280, 480, 1920
 ALGO = {  # short kernel name -> (read MB per call, written MB per call, what)
     "ln_modulate_fwd8_kernel": ((BT * D * 6) / 1e6, (BT * D * 6) / 1e6, "x f32 + y bf16 -> x' f32 + u bf16"),
     "ln_modulate_bwd8_kernel": ((BT * D * 12) / 1e6, (BT * D * 6) / 1e6, "du bf16 + x f32 + dx f32 + y bf16 -> dx f32 + dy bf16"),
+    "ln_modulate_bwd8v2_kernel": ((BT * D * 12) / 1e6, (BT * D * 6) / 1e6, "du bf16 + x f32 + dx f32 + y bf16 -> dx f32 + dy bf16 (round-4 form)"),
+    "adamw_sched_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),
+    "gemm<bf16,fwd,128x128x64,GELU>": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "u2 + W -> h + gelu' (128 x 128 tiles)"),
+    "gemm<bf16,dgrad,128x128x64,DGELU>": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "dy + W + gelu' -> dh (128 x 128 tiles)"),
     "attn_fwd_dense_kernel": ((BT * 3 * D * 2) / 1e6, (BT * D * 2) / 1e6, "qkv -> o"),
     "attn_bwd_fused_kernel": ((BT * 5 * D * 2) / 1e6, (BT * 3 * D * 2) / 1e6, "qkv + o + dO -> dqkv"),
     "adamw_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),

@@ -555,8 +555,7 @@ extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void
     p->evUp.push_back(e);
   }
   hipStream_t st = c.s;
-  static const bool on_main = getenv("V4H_UPD_ON_MAIN") && getenv("V4H_UPD_ON_MAIN")[0] == '1';  // diagnostic: the staged update in line
-  const bool side = g_overlap_wgrad && !on_main;
+  const bool side = g_overlap_wgrad;
   if (side) {
     RUN(side_wait_main(*p, c.s));
     st = p->side;
