@@ -205,8 +205,8 @@ int gemm_wgrad_splitk(Mode m, int I, int J, int K) {
     const int tiles = ((I + 95) / 96) * ((J + 159) / 160);
     sk = tiles >= 40 ? 8 : 16;
     if (tiles < 8) sk = 32;
-    static const int small_sk = env_flag("V4H_WGRAD_SMALL_SPLITS", 0);  // A/B hook: K splits of the mid-sized weight gradients (attn.proj: 15 tiles)
-    if (small_sk > 0 && tiles >= 8 && tiles < 40) sk = small_sk;
+    // (Round 4, measured neutral: 24 / 32 / 34 splits for the 15-tile attn.proj gradient - 480 instead of 240 workgroups on the 512 slots - and the ring
+    //  kernel with 16 / 32 / 40 splits for it: 243.0 ... 244.6 against 243.3 steps/s.)
   }
   const int maxk = K / 128;  // at least two K-steps of 64 per split
   if (sk > maxk) sk = maxk;
