@@ -555,13 +555,14 @@ def main():
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
-        # host time to ENQUEUE one step on an idle device (the queue empty, nothing to wait for): below ms_per_step = the device sets the pace
-        sync()
-        th = time.perf_counter()
-        for _ in range(3):
-            trainer.step(x, c)
-        rec["host_enqueue_ms_per_step"] = round((time.perf_counter() - th) * 1e3 / 3, 3)
-        sync()
+        if not args.lean:  # (profiling runs count the steps of the process: no extra ones)
+            # host time to ENQUEUE one step on an idle device (the queue empty, nothing to wait for): below ms_per_step = the device sets the pace
+            sync()
+            th = time.perf_counter()
+            for _ in range(3):
+                trainer.step(x, c)
+            rec["host_enqueue_ms_per_step"] = round((time.perf_counter() - th) * 1e3 / 3, 3)
+            sync()
         rec["roofline"]["traffic_source"] = ("profiles/step_hbm_traffic.json (builder-measured PMC passes over this program, digest-matched to the kernel "
                                              "sources of this build; not measured in this run)")
         if traffic_note:
