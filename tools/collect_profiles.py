@@ -18,8 +18,8 @@ if os.path.exists(f"{R}/ab_in_context.txt"):
     open(f"profiles/{rp}_ab_in_context_{tag}.txt", "w").write(
         "# In-context A/B of the switches the library keeps (tools/refresh_profiles.sh, part 3): two interleaved rounds on one box, each line one full `bench.py` run\n"
         "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default build.  Round-4 levers switched off one at a time: V4H_MLP_TILE=0 (GELU / DGELU contractions\n"
-        "# on 128 x 160 tiles again), V4H_LNB_V2=0 (round-2 LayerNorm backward), V4H_PREPARE_AHEAD=0 (operand casts inside the forward); round-4 options measured neutral and left\n"
-        "# off: V4H_LNF_V2=1, V4H_PIPELINE_UPDATE=1, V4H_ASYNC_T=1 (the last costs a one-time 18-35 ms runtime stall when the host first runs ahead - it lands in these 40 steps);\n"
+        "# on 128 x 160 tiles again), V4H_LNB_V2=0 (round-2 LayerNorm backward); round-4 options measured neutral and left off: V4H_LNF_V2=1, V4H_PREPARE_AHEAD=1 (operand casts on\n"
+        "# the side stream at the start of the step), V4H_PIPELINE_UPDATE=1, V4H_ASYNC_T=1 (costs a one-time 18-35 ms runtime stall when the host first runs ahead; here it falls into the warm-up);\n"
         "# then the older switches: 0 / 8 = two-workgroup / ring kernel everywhere, whole-K kernels off, round-2 attention, 4 K-splits, per-block adaLN, no weight-gradient stream.\n"
         + open(f"{R}/ab_in_context.txt").read())
 if os.path.exists(f"{R}/gemm2_ablation.txt"):

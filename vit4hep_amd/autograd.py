@@ -134,14 +134,17 @@ def plan_join(net, device):
 
 
 @_on_device_of(4)
-def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=None):
+def run_backward(net, params, grads, dout_vox, ws, stage_first=0, stage_last=None, tables=None):
+    """``tables``: (parameter pointer table, gradient pointer table) made once by the caller of a staged pass (building two ctypes arrays of 75
+    pointers per stage call is a measurable share of a host-bound step)."""
     plan = net._get_plan()
     B = dout_vox.shape[0] if dout_vox is not None else None
     if stage_last is None:
         stage_last = plan.num_stages - 1
     pmap, pos = net.device_tables(ws.device)
+    ptab, gtab = tables if tables is not None else (_lib.pointer_table(params), _lib.pointer_table(grads))
     _lib.check(
-        _lib.load().v4h_vit_backward(plan.handle, B, _lib.pointer_table(params), _lib.pointer_table(grads), _lib.ptr(dout_vox), _lib.ptr(ws), ws.numel(),
+        _lib.load().v4h_vit_backward(plan.handle, B, ptab, gtab, _lib.ptr(dout_vox), _lib.ptr(ws), ws.numel(),
                                      stage_first, stage_last, _lib.stream_ptr(ws.device), _lib.ptr(pmap), _lib.ptr(pos)),
         "v4h_vit_backward",
     )
@@ -216,7 +219,7 @@ STAGE_LOG = None  # tests: a list that receives ("stage", s) when backward stage
 class _Pass:
     """State shared by the nodes of one forward / backward pass."""
 
-    __slots__ = ("net", "ws", "patches_io", "params", "grads", "dout", "out", "carrier_grad", "depth")
+    __slots__ = ("net", "ws", "patches_io", "params", "grads", "dout", "out", "carrier_grad", "depth", "tables")
 
 
 def _stage_param_slices(net, nparams):
@@ -231,7 +234,9 @@ def _stage_param_slices(net, nparams):
 def _run_stage(ps, stage):
     if STAGE_LOG is not None:
         STAGE_LOG.append(("stage", stage))
-    run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage)
+    if ps.tables is None:
+        ps.tables = (_lib.pointer_table(ps.params), _lib.pointer_table(ps.grads))
+    run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage, tables=ps.tables)
 
 
 class _StageEmbed(torch.autograd.Function):
@@ -305,7 +310,7 @@ def _apply_staged(net, x, t, c, patches_io, params):
         raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {_vox_shape(net, x_vox.shape[0])}")
     ps = _Pass()
     ps.net, ps.patches_io, ps.params, ps.depth = net, patches_io, [p.detach() for p in params], int(net.depth)
-    ps.ws = ps.grads = ps.dout = ps.out = ps.carrier_grad = None
+    ps.ws = ps.grads = ps.dout = ps.out = ps.carrier_grad = ps.tables = None
     first, blocks, final = _stage_param_slices(net, len(params))
     carrier = _StageEmbed.apply(ps, x_vox, t, c, first, *[params[i] for i in first])
     for i, idx in enumerate(blocks):
