@@ -555,7 +555,7 @@ def main():
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
-        if not args.lean:  # (profiling runs count the steps of the process: no extra ones)
+        if not args.lean and world == 1:  # (profiling runs count the steps of the process: no extra ones; with several ranks a step is a collective)
             # host time to ENQUEUE one step on an idle device (the queue empty, nothing to wait for): below ms_per_step = the device sets the pace
             sync()
             th = time.perf_counter()
