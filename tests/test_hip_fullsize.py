@@ -147,3 +147,11 @@ def test_full_size_ds2_gradients_match_the_oracle(mode):
 def test_full_size_ds3_gradients_match_the_oracle():
     """BASELINE config 3: ds3 shape model (450 tokens of 90), depth 6, B = 64, bf16 - every gradient tensor, rms <= 3e-2."""
     _compare_with_oracle(O.ds3(6), 64, "bf16", 43)
+
+
+@pytest.mark.parametrize("batch,mode", [(1, "bf16"), (3, "f32"), (17, "bf16"), (33, "bf16"), (65, "f32"), (100, "bf16"), (129, "bf16"), (200, "bf16"), (257, "bf16")])
+def test_ragged_batch_sizes_match_the_oracle(batch, mode):
+    """Batch sizes that are no multiple of anything: the row count B * 135 never fills the last tile, the per-call tile shape of the N = 1920
+    contractions (csrc/v4h_gemm.hip: pick_mlp_tile) and the contraction kernel itself (ring kernel from 2048 rows on) change with it, the weight
+    gradients' K splits get ragged tails.  ds2 shape model, depth 2; every gradient tensor against the oracle."""
+    _compare_with_oracle(O.ds2(2), batch, mode, 50 + batch)
