@@ -453,6 +453,7 @@ class CFMTrainer:
             t.copy_(torch.tensor(new, dtype=torch.int32))
         self.nonfinite.zero_()
         self.step_count = new[0]
+        self._graph = None  # a captured step (use_graph) has the old hyper-parameters as kernel arguments: capture again
 
     @staticmethod
     def check_finite(grad_norm):
