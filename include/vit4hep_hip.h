@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 9
+#define V4H_ABI_VERSION 10
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -121,6 +121,13 @@ int32_t v4h_vit_update_ahead(const v4h_plan* plan, int32_t B, const void* const*
                              const int32_t* d_state_in, int32_t* d_state_out, int32_t* d_nonfinite, float* d_gnorm_out, void* stream, const float* d_pos);
 /* `stream` waits for everything the plan's side stream holds (a pipelined update, operand copies made ahead). */
 int32_t v4h_plan_join(const v4h_plan* plan, void* stream);
+/* Gradient mode of v4h_vit_backward / v4h_vit_backward_events on this plan.  0 (default): gradients are ACCUMULATED into d_grads - what autograd's
+ * `.grad +=` and the reference's `optimizer.zero_grad(); loss.backward()` (experiments/base_experiment.py:559-560) need; the caller zeroes (or keeps
+ * accumulating into) the tensors.  1: every gradient tensor of the stages a call runs is WRITTEN by that call, whatever it held before - the reduce pass
+ * of the split-K partials of a block's four Linear weights stores instead of adding (no read-modify-write of zeros), the tensors that are accumulated
+ * into with atomics are zeroed by the call itself, in the launch that zeroes its workspace accumulators anyway: an update loop that owns its gradient
+ * buffer (vit4hep_amd/trainer.py) drops its zero fill of all gradients (104 MB per step at ds2).  Same values either way (bitwise for the weights). */
+int32_t v4h_plan_set_gradient_mode(const v4h_plan* plan, int32_t mode);
 /* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
  * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
  * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce

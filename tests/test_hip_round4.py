@@ -406,3 +406,49 @@ def test_pipelined_update_is_bit_identical_on_identical_gradients():
         outs.append((tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_v.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------- gradients written, not accumulated
+@pytest.mark.parametrize("mode,batch", [("f32", 4), ("bf16", 4), ("bf16", 40)])
+def test_backward_overwrites_a_poisoned_gradient_buffer(mode, batch):
+    """v4h_plan_set_gradient_mode(1) (what CFMTrainer uses): the pass writes every gradient, so a gradient buffer full of NaN / stale values gives the
+    gradients of the zero-fill + accumulate form - bit for bit where that form is deterministic (the weight gradients reduced from split-K slabs), to
+    float-atomic reordering elsewhere; the padding between the tensors stays zero; and the plan is back in accumulate mode afterwards."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    x, c, noise = _data(cfg, batch, 47, 1)
+    t, x0 = noise[0]
+    res = {}
+    for overwrite in (False, True):
+        model = U.build_models(cfg, mode, O.golden_fill(cfg))
+        tr = CFMTrainer(model, iterations=40)
+        tr.overwrite_grads = overwrite
+        if overwrite:
+            for lo, p in zip(tr.offsets, tr.params):
+                tr.flat_g[lo : lo + p.numel()] = float("nan")  # (the padding keeps its zeros, as in a run)
+        loss = tr.loss_and_grads(x, c, t, x0)
+        res[overwrite] = (loss.item(), tr.flat_g.clone(), [n for n, _ in model.named_parameters()], tr)
+    (l0, g0, names, tr0), (l1, g1, _, tr1) = res[False], res[True]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)  # (the bf16 forward sums the conditioning terms with float atomics: last-bit differences between two runs)
+    assert torch.isfinite(g1).all()
+    order = {p.data_ptr(): n for n, p in tr1.model.named_parameters()}
+    for lo, p in zip(tr1.offsets, tr1.params):
+        a, b = g0[lo : lo + p.numel()], g1[lo : lo + p.numel()]
+        name = order.get(p.data_ptr(), "?")
+        if mode == "f32" and p.dim() == 2 and ".blocks." in name and "adaLN" not in name and batch * 135 >= 256:  # split-K slabs: deterministic
+            assert torch.equal(a, b), name
+        else:
+            assert U.rms_err(b, a) < (1e-5 if mode == "f32" else 1e-3), name
+    pad = torch.ones_like(g1, dtype=torch.bool)
+    for lo, p in zip(tr1.offsets, tr1.params):
+        pad[lo : lo + p.numel()] = False
+    assert float(g1[pad].abs().max()) == 0.0 if pad.any() else True
+    # the shared plan accumulates again: the autograd node on the same network still matches
+    model = tr1.model
+    model.zero_grad(set_to_none=True)
+    la = model._loss_from_noise(x.to(U.DEV), c.to(U.DEV), t.to(U.DEV), x0.to(U.DEV))
+    la.backward()
+    for n, p in model.named_parameters():
+        lo = tr1.offsets[[q.data_ptr() for q in tr1.params].index(p.data_ptr())]
+        assert U.rms_err(p.grad.reshape(-1), g1[lo : lo + p.numel()]) < (1e-5 if mode == "f32" else 1e-3), n

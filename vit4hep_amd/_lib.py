@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -66,6 +66,7 @@ SIGNATURES = {
     "v4h_vit_update_ahead": (_i32, [_vp, _i32, _pp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int64), _vp, _sz, _vp, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32, _f32,
                                     _vp, _vp, _vp, _vp, _vp, _vp]),
     "v4h_plan_join": (_i32, [_vp, _vp]),
+    "v4h_plan_set_gradient_mode": (_i32, [_vp, _i32]),
     "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_backward_events": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _vp, _vp, _vp, _pp]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),

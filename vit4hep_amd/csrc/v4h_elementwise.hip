@@ -1007,12 +1007,22 @@ __global__ void rk4_combine_kernel(float* __restrict__ y, const float* __restric
 }
 
 // out[k] += sum_z slab[z][k]: the second half of a split-K weight gradient (deterministic, unlike float atomics)
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n4, float* __restrict__ out) {
+// SET: out[k] = sum_z slab[z][k] (the gradient tensor need not be initialised: v4h_plan_set_gradient_mode)
+template <bool SET> __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n4, float* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 acc = load4(out + 4 * i);
+    f32x4 acc = SET ? f32x4{0.f, 0.f, 0.f, 0.f} : load4(out + 4 * i);
     for (int z = 0; z < nz; ++z) acc += load4(slab + ((long)z * n4 + i) * 4);
     store4(out + 4 * i, acc);
   }
+}
+
+// several buffers zeroed by one launch (gradient tensors that are accumulated into + the workspace accumulators of a backward pass)
+__global__ void zero_many_kernel(const ZeroTable tb) {
+  float* p = tb.p[blockIdx.y];
+  const long n = tb.n[blockIdx.y], n4 = n / 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) store4(p + 4 * i, z);
+  if (blockIdx.x == 0 && threadIdx.x < n - 4 * n4) p[4 * n4 + threadIdx.x] = 0.f;
 }
 
 inline int nblocks(long n, int per_block, int cap = 2048) {
@@ -1305,10 +1315,26 @@ int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const
   const AdamwHyper h{clip, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm};
   return adamw_step_ranges(p, g, m, v, &lo, &n, 1, h, gnorm_sq, state_in, state_out, nonfinite, gnorm_out, true, s);
 }
-int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s) {
+int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s, bool set) {
   V4H_CHECK_ARG(n % 4 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)slab % 16) == 0, "slab_reduce: size / alignment");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
+  if (set) hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
+  else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
   V4H_CHECK_LAUNCH("slab_reduce");
+  return V4H_OK;
+}
+int zero_many(const std::pair<float*, long>* items, int n, hipStream_t s) {
+  for (int base = 0; base < n; base += ZERO_MAX_ITEMS) {
+    ZeroTable tb;
+    const int cnt = (n - base) < ZERO_MAX_ITEMS ? (n - base) : ZERO_MAX_ITEMS;
+    for (int e = 0; e < ZERO_MAX_ITEMS; ++e) {
+      const bool live = e < cnt;
+      tb.p[e] = live ? items[base + e].first : nullptr;
+      tb.n[e] = live ? items[base + e].second : 0;
+      V4H_CHECK_ARG(!live || (tb.p[e] != nullptr && tb.n[e] >= 0 && ((uintptr_t)tb.p[e] % 16) == 0), "zero_many: item %d null, negative or not 16-byte aligned", base + e);
+    }
+    hipLaunchKernelGGL(zero_many_kernel, dim3(32, cnt), dim3(256), 0, s, tb);
+    V4H_CHECK_LAUNCH("zero_many");
+  }
   return V4H_OK;
 }
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s) {

@@ -63,6 +63,9 @@ struct EpiArgs {
   // overhead); group_rows must be a multiple of 16; 0 = off.
   int group_rows;
   float* const* group_tab;
+  // EPI_ATOMIC_F32 without K splits: every output element has exactly one writer - `store` makes it a plain store (the output need not be zeroed, and
+  // the 35 MB of adaLN weight gradients leave the chip at the store rate instead of the float-atomic rate).  Column sums stay atomic.
+  int store;
 };
 
 struct GemmArgs {
@@ -689,9 +692,14 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         const int gi = ib / a.e.group_rows;  // a 16-row strip never straddles two groups
         outp = a.e.group_tab[gi] + (size_t)(ib - gi * a.e.group_rows) * a.e.ldo;
       }
+      const bool plain = a.e.store != 0 && a.nz == 1;  // (uniform)
       for (int id = lane; id < 16 * C::WTJ; id += 64) {
         const int row = id / C::WTJ, col = id % C::WTJ;
-        if (ib + row < a.I && jb + col < a.J) atomicAdd(outp + (size_t)row * a.e.ldo + jb + col, strip[row * SLD + col]);
+        if (ib + row < a.I && jb + col < a.J) {
+          float* dst = outp + (size_t)row * a.e.ldo + jb + col;
+          if (plain) *dst = strip[row * SLD + col];
+          else atomicAdd(dst, strip[row * SLD + col]);
+        }
       }
       __syncthreads();
     }

@@ -1,6 +1,7 @@
 // Internal C++ interface between the kernel translation units and the runtime (v4h_runtime.hip).
 // Everything here takes raw device pointers + a hipStream_t; the public C ABI is include/vit4hep_hip.h.
 #pragma once
+#include <utility>
 #include "v4h_gemm.h"
 
 namespace v4h {
@@ -14,7 +15,10 @@ int gemm_dgrad(Mode m, int epi, const GemmArgs& a, hipStream_t s, int splitk = 1
 int gemm_wgrad(Mode m, const GemmArgs& a, int splitk, hipStream_t s);         // both K-strided, f32 atomics (+ colsum)
 int gemm_wgrad_splitk(Mode m, int I, int J, int K);  // the split count the runtime uses for a weight gradient of this shape
 int gemm_wgrad_slab(Mode m, const GemmArgs& a, int splitk, float* slab, int* nz_out, hipStream_t s);  // partials [nz][I][J], plain stores
-int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s);  // out[k] += sum_z slab[z*n + k]
+int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s, bool set = false);  // out[k] (+)= sum_z slab[z*n + k]; set: plain store
+constexpr int ZERO_MAX_ITEMS = 64;
+struct ZeroTable { float* p[ZERO_MAX_ITEMS]; long n[ZERO_MAX_ITEMS]; };
+int zero_many(const std::pair<float*, long>* items, int n, hipStream_t s);  // items[i] = (16-byte aligned buffer, floats): all zeroed by one launch per 64
 
 int select_contraction_kernel(int which);  // 0 automatic, 1 two-workgroup kernel everywhere, 2 ring kernel wherever eligible (all exact)
 int selected_contraction_kernel();

@@ -62,6 +62,7 @@ struct v4h_plan {
   mutable unsigned long long upd_mask = 0;  // stages whose event the next forward still has to wait for
   mutable int evi = 0;
   mutable bool side_ok = false;
+  mutable bool grad_overwrite = false;  // v4h_plan_set_gradient_mode: backward passes WRITE every gradient of their stages (caller need not zero)
   mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
 };
 
@@ -436,22 +437,29 @@ static GemmArgs gargs(const void* P, int ldp, const void* Q, int ldq, int I, int
   return a;
 }
 
-// dW[I][J] += dY^T X  (+ db[I] += column sums of dY)
-static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db, hipStream_t s = nullptr) {
+// Does the weight gradient of this shape go through split-K partial slabs + one reduce pass (else: f32 atomics / accumulation straight into dW)?
+static bool wgrad_takes_slab(const v4h_plan& p, int I, int J, int K, int ldo) {
+  const int sk = gemm_wgrad_splitk(p.mode, I, J, K);
+  return sk > 1 && ldo == J && (size_t)sk * I * J * 4 <= slab_bytes(p) && (I * (long)J) % 4 == 0;
+}
+// dW[I][J] += dY^T X  (+ db[I] += column sums of dY).  `set` (only where wgrad_takes_slab): dW = dY^T X, whatever dW held before.
+static int wgrad(const Ctx& c, const void* dY, int ld_dy, int I, const void* X, int ld_x, int J, int K, float* dW, int ldo, float* db, hipStream_t s = nullptr,
+                 bool set = false) {
   GemmArgs a = gargs(dY, ld_dy, X, ld_x, I, J, K);
   a.e.out = dW; a.e.ldo = ldo; a.colsum = db;
   const int sk = gemm_wgrad_splitk(c.p.mode, I, J, K);
   hipStream_t st = s ? s : c.s;
   // Split-K partial sums: plain coalesced stores into a slab + one reduce pass instead of sk-fold f32 atomics (which run
   // at ~1.3 TB/s at the memory side): faster, and the weight gradient is bitwise reproducible.
-  if (sk > 1 && ldo == J && (size_t)sk * I * J * 4 <= slab_bytes(c.p) && (I * (long)J) % 4 == 0) {
+  if (wgrad_takes_slab(c.p, I, J, K, ldo)) {
     // one scratch slab per queue (main: 0, side: 1): calls on one stream are ordered, calls on the two streams never share a slab
     V4H_CHECK_ARG(st == c.s || st == c.p.side, "wgrad: stream is neither the caller's nor the plan's side stream (no split-K scratch for it)");
     float* slab = c.w.slab[st == c.s ? 0 : 1];
     int nz = 1;
     RUN(gemm_wgrad_slab(c.p.mode, a, sk, slab, &nz, st));
-    return slab_reduce(slab, nz, (long)I * J, dW, st);
+    return slab_reduce(slab, nz, (long)I * J, dW, st, set);
   }
+  V4H_CHECK_ARG(!set, "wgrad: overwrite requested for a shape that accumulates (I=%d J=%d K=%d)", I, J, K);
   return gemm_wgrad(c.p.mode, a, sk, st);
 }
 
@@ -590,6 +598,13 @@ extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void
 }
 // `stream` waits for everything the plan's side stream holds (a pipelined update, operand copies made ahead): call before the parameters, the moments or
 // the workspace are touched from `stream` by anything but the next v4h_vit_forward.
+// Gradient mode of the plan's backward passes: 0 (default) = gradients are ACCUMULATED into the caller's tensors (the caller zeroes them, or
+// accumulates over several passes); 1 = every gradient tensor of the stages a call runs is WRITTEN by that call, whatever it held before.
+extern "C" int32_t v4h_plan_set_gradient_mode(const v4h_plan* p, int32_t mode) {
+  V4H_CHECK_ARG(p != nullptr && (mode == 0 || mode == 1), "plan_set_gradient_mode: null plan or mode %d not 0 (accumulate) / 1 (overwrite)", mode);
+  p->grad_overwrite = mode == 1;
+  return V4H_OK;
+}
 extern "C" int32_t v4h_plan_join(const v4h_plan* p, void* stream) {
   V4H_CHECK_ARG(p != nullptr, "plan_join: null plan");
   if (!p->side_ok) return V4H_OK;
@@ -832,10 +847,40 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   auto dmod = [&](int i) { return w.dmod_base + (batch_ada ? (size_t)i * 6 * D : (size_t)i * B * 6 * D); };
   float* const dmodf = dmod(depth);
 
+  // Gradient mode "overwrite" (v4h_plan_set_gradient_mode): the four Linear weights of a block - 64 % of all gradient elements - are STORED by the
+  // reduce pass of their split-K partials (no read-modify-write of zeros), and everything that is accumulated into (bias column sums, adaLN,
+  // embedders, final layer) is zeroed here, by the one launch that also zeroes the workspace accumulators: the caller's 104 MB fill disappears.
+  const bool overwrite = p->grad_overwrite;
+  const bool set_qkv = overwrite && wgrad_takes_slab(*p, 3 * D, D, BT, D), set_proj = overwrite && wgrad_takes_slab(*p, D, D, BT, D);
+  const bool set_fc1 = overwrite && wgrad_takes_slab(*p, M, D, BT, D), set_fc2 = overwrite && wgrad_takes_slab(*p, D, M, BT, M);
+  if (overwrite) {
+    std::vector<std::pair<float*, long>> zl;
+    auto add = [&](int i) { zl.emplace_back((float*)grads[i], (long)p->rows[i] * (p->cols[i] ? p->cols[i] : 1)); };
+    for (int st = stage_first; st <= stage_last; ++st) {
+      if (st == 0) {
+        zl.emplace_back((float*)w.zero_begin, (long)(w.zero_bytes / 4));
+        for (int k = 0; k < F_COUNT; ++k)
+          if (!(k == F_ADAW && batch_ada)) add(p->fin(k));
+      } else if (st <= depth) {
+        const int i = depth - st;
+        for (int k = 0; k < B_COUNT; ++k) {
+          const bool set = (k == B_QKVW && set_qkv) || (k == B_PROJW && set_proj) || (k == B_FC1W && set_fc1) || (k == B_FC2W && set_fc2) ||
+                           (k == B_ADAW && batch_ada);  // (the grouped adaLN contraction of a whole pass stores its weight gradients)
+          if (!set) add(p->blk(i, k));
+        }
+      } else {
+        for (int i = 0; i < P_BLOCK0; ++i) add(i);
+        for (int i = p->fin(0) + F_COUNT; i < p->nparams(); ++i) add(i);  // fine-tuning mappers
+      }
+    }
+    RUN(zero_many(zl.data(), (int)zl.size(), c.s));
+  }
   for (int st = stage_first; st <= stage_last; ++st) {
     if (st == 0) {
-      hipError_t e = hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, c.s);
-      if (e != hipSuccess) { v4h_set_error("vit_backward: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+      if (!overwrite) {
+        hipError_t e = hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, c.s);
+        if (e != hipSuccess) { v4h_set_error("vit_backward: memset failed: %s", hipGetErrorString(e)); return V4H_ERR_HIP; }
+      }
       if (pmap) RUN(patchify_map(m, false, dout, pmap, w.dvp, B, p->V, T, p->P, p->Ppad, c.s));
       else RUN(patchify(m, dout, w.dvp, B, p->pg, p->P, p->Ppad, c.s));
       const bool ov0 = g_overlap_wgrad;
@@ -873,10 +918,10 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       // streams interleave matters more than the packets.]
       auto wg = [&](int k) -> int {
         switch (k) {
-          case 0: return wgrad(c, dy_i, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_);
-          case 1: return wgrad(c, dh_i, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_);
-          case 2: return wgrad(c, dy2_i, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_);
-          default: return wgrad(c, dq_i, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_);
+          case 0: return wgrad(c, dy_i, D, D, b.h, M, M, BT, (float*)grads[p->blk(i, B_FC2W)], M, (float*)grads[p->blk(i, B_FC2B)], ws_, set_fc2);
+          case 1: return wgrad(c, dh_i, M, M, b.u2, D, D, BT, (float*)grads[p->blk(i, B_FC1W)], D, (float*)grads[p->blk(i, B_FC1B)], ws_, set_fc1);
+          case 2: return wgrad(c, dy2_i, D, D, b.o, D, D, BT, (float*)grads[p->blk(i, B_PROJW)], D, (float*)grads[p->blk(i, B_PROJB)], ws_, set_proj);
+          default: return wgrad(c, dq_i, 3 * D, 3 * D, b.u1, D, D, BT, (float*)grads[p->blk(i, B_QKVW)], D, (float*)grads[p->blk(i, B_QKVB)], ws_, set_qkv);
         }
       };
       auto fork_wgrad = [&](int k) -> int {  // one weight gradient on the side stream as soon as its dY exists
@@ -959,6 +1004,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
         }
         RUN(write_ptr_table(tab, w.gtab, sx));  // the gradient tensors may move between calls: the table is rewritten every time
         a.e.group_tab = w.gtab; a.e.out = tab.p[0]; a.colsum = tab.p[V4H_GEMM_MAX_GROUPS];
+        a.e.store = overwrite ? 1 : 0;  // one writer per element (no K split): a plain store where the pass owns the gradient tensors
         RUN(gemm_wgrad(m, a, 1, sx));
       }
       RUN(wgrad(c, w.dx0_t, D, D, w.xp, p->Pxpad, p->Pxpad, BT, w.gxw, p->Pxpad, (float*)grads[P_XB], sx));

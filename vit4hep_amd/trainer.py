@@ -130,6 +130,8 @@ class CFMTrainer:
         # start of a step and the forward waits for them only in front of its first weight-consuming kernel, so that they run beside the step's head (noise,
         # trajectory, patch gather).  Measured neutral over four same-box A/Bs (237.3 vs 237.5 steps/s on average): off, the casts stay inside the forward.
         self.prepare_ahead = os.environ.get("V4H_PREPARE_AHEAD", "0") == "1"
+        # V4H_OVERWRITE_GRADS=0: A/B hook - zero the gradient buffer every step and let the backward accumulate (the form of rounds 1-3)
+        self.overwrite_grads = os.environ.get("V4H_OVERWRITE_GRADS", "1") != "0"
         # [applied optimizer steps, scheduler steps, updates skipped for max_grad_norm, -] on the device, two copies used alternately (the update kernel
         # reads one and writes the other: include/vit4hep_hip.h, v4h_adamw_step_sched)
         st = getattr(self, "_state", None)
@@ -215,7 +217,25 @@ class CFMTrainer:
         W = world()
         if W > 1:  # DDP averages gradients: fold 1/world into the seed, then SUM
             _lib.check(lib.v4h_axpby(_lib.ptr(dv), _lib.ptr(dv), _lib.ptr(dv), 1.0 / W, 0.0, dv.numel(), s), "v4h_axpby")
-        self.flat_g.zero_()
+        # The gradient buffer is this class's own and is used for nothing else: the backward WRITES every gradient (v4h_plan_set_gradient_mode 1: the
+        # reduce pass of a weight gradient's split-K partials stores instead of adding, the tensors accumulated into are zeroed by the pass itself) -
+        # no 104 MB zero fill per step, no read-modify-write of zeros.  The padding between tensors keeps its zeros from _flatten().  The plan is shared
+        # with the autograd node (which accumulates into caller-owned tensors): the mode is set for this pass only.
+        plan_h = self.net._get_plan().handle
+        overwrite = self.overwrite_grads
+        if overwrite:
+            _lib.check(lib.v4h_plan_set_gradient_mode(plan_h, 1), "v4h_plan_set_gradient_mode")
+        else:
+            self.flat_g.zero_()
+        try:
+            self._backward(dv, ws)
+        finally:
+            if overwrite:
+                lib.v4h_plan_set_gradient_mode(plan_h, 0)
+        return self.loss
+
+    def _backward(self, dv, ws):
+        lib = _lib.load()
         if collectives_enabled() and os.environ.get("V4H_STAGED_CALLS") != "1":
             # one call; the library records an event when a stage's gradient slice is final and the bucket is reduced behind it
             if self.stage_events is None:
@@ -238,7 +258,6 @@ class CFMTrainer:
             self.reducer.finish()
         else:  # single rank: one call, so the weight-gradient stream is joined only once at the end
             run_backward(self.net, self.p_views, self.g_views, dv, ws, 0, len(self.stage_slices) - 1)
-        return self.loss
 
     def step(self, x, c, t=None, x0=None):
         """One BaseExperiment._step.  Returns (loss, grad_norm) as 0-dim device tensors (pre-clip norm, like clip_grad_norm_)."""
