@@ -1008,10 +1008,19 @@ __global__ void rk4_combine_kernel(float* __restrict__ y, const float* __restric
 
 // out[k] += sum_z slab[z][k]: the second half of a split-K weight gradient (deterministic, unlike float atomics)
 // SET: out[k] = sum_z slab[z][k] (the gradient tensor need not be initialised: v4h_plan_set_gradient_mode)
+// The partials are requested eight at a time and added in their order (with a run-time trip count and one load per iteration a lane waits for each partial in
+// turn: 33 dependent round trips for the 32 splits of the small embedder gradients - 20 us for 4 MB, in the tail of the step).
 template <bool SET> __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nz, long n4, float* __restrict__ out) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 acc = SET ? f32x4{0.f, 0.f, 0.f, 0.f} : load4(out + 4 * i);
-    for (int z = 0; z < nz; ++z) acc += load4(slab + ((long)z * n4 + i) * 4);
+    for (int z0 = 0; z0 < nz; z0 += 8) {
+      f32x4 part[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] = load4(slab + ((long)min(z0 + u, nz - 1) * n4 + i) * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (z0 + u < nz) acc += part[u];
+    }
     store4(out + 4 * i, acc);
   }
 }
@@ -1044,7 +1053,7 @@ int cast_pad_many(Mode m, const CastPadItem* items, int n, hipStream_t s) {
       tb.first_block[e] = nb;
       const long total = (long)tb.it[e].Rp * tb.it[e].Cp;
       V4H_CHECK_ARG(total > 0, "cast_pad: empty item %d", base + e);
-      nb += nblocks(total, 1024, 256);
+      nb += nblocks(total, 1024, n == 1 ? 2048 : 256);  // (a lone item - the d-modulation table of the backward, 2.3 M elements - would walk 9 dependent rounds on 256 blocks)
     }
     tb.first_block[tb.n] = nb;
     if (m == MODE_BF16) hipLaunchKernelGGL(cast_pad_kernel<bf16>, dim3(nb), dim3(256), 0, s, tb);
@@ -1317,8 +1326,9 @@ int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const
 }
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s, bool set) {
   V4H_CHECK_ARG(n % 4 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)slab % 16) == 0, "slab_reduce: size / alignment");
-  if (set) hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
-  else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(nblocks(n / 4, 256)), dim3(256), 0, s, slab, nz, n / 4, out);
+  const int bs = n / 4 >= 65536 ? 256 : 64;  // small results (embedder gradients: 7680 float4 of 32 partials each) spread over more CUs
+  if (set) hipLaunchKernelGGL(slab_reduce_kernel<true>, dim3(nblocks(n / 4, bs)), dim3(bs), 0, s, slab, nz, n / 4, out);
+  else hipLaunchKernelGGL(slab_reduce_kernel<false>, dim3(nblocks(n / 4, bs)), dim3(bs), 0, s, slab, nz, n / 4, out);
   V4H_CHECK_LAUNCH("slab_reduce");
   return V4H_OK;
 }
