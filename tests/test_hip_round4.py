@@ -452,3 +452,26 @@ def test_backward_overwrites_a_poisoned_gradient_buffer(mode, batch):
     for n, p in model.named_parameters():
         lo = tr1.offsets[[q.data_ptr() for q in tr1.params].index(p.data_ptr())]
         assert U.rms_err(p.grad.reshape(-1), g1[lo : lo + p.numel()]) < (1e-5 if mode == "f32" else 1e-3), n
+
+
+def test_bounded_host_run_ahead_changes_nothing():
+    """CFMTrainer.max_steps_ahead (default 2): the host waits for the step issued that many steps ago before it enqueues the next one - same trajectory as
+    the unbounded loop, never more than that many events outstanding."""
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    x, c, noise = _data(cfg, 4, 57, 5)
+    out = []
+    for ahead in (0, 1, 2):
+        model = U.build_models(cfg, "f32", O.golden_fill(cfg))
+        tr = CFMTrainer(model, iterations=40)
+        tr.max_steps_ahead = ahead
+        rec = []
+        for t, x0 in noise:
+            loss, gn = tr.step(x, c, t, x0)
+            assert len(tr._ahead_events) <= ahead
+            rec.append((loss, gn))
+        out.append([(float(a), float(b)) for a, b in rec])
+    for other in out[1:]:
+        for (l0, g0), (l1, g1) in zip(out[0], other):
+            assert abs(l0 - l1) <= 2e-6 * abs(l0) and abs(g0 - g1) <= 2e-5 * abs(g0)

@@ -132,6 +132,13 @@ class CFMTrainer:
         self.prepare_ahead = os.environ.get("V4H_PREPARE_AHEAD", "0") == "1"
         # V4H_OVERWRITE_GRADS=0: A/B hook - zero the gradient buffer every step and let the backward accumulate (the form of rounds 1-3)
         self.overwrite_grads = os.environ.get("V4H_OVERWRITE_GRADS", "1") != "0"
+        # The host enqueues a step in a quarter of the time the device needs for it, and nothing in step() waits for the device: an update loop that never
+        # reads a result runs dozens of steps (thousands of launches) ahead.  The HIP runtime then grows its signal / kernel-argument pools ONCE, at an
+        # unpredictable early step, and the device sits idle for 30-60 ms meanwhile (measured: step 0 ... 4 of a timed region taking 27-62 ms instead of
+        # 4.2; profiles/r04_notes.md).  The host therefore stays at most `max_steps_ahead` steps ahead (one event per step, waited for that many steps
+        # later): the same steady-state rate, no stall.  0 = unbounded (V4H_MAX_STEPS_AHEAD).
+        self.max_steps_ahead = int(os.environ.get("V4H_MAX_STEPS_AHEAD", "2"))
+        self._ahead_events = []
         # [applied optimizer steps, scheduler steps, updates skipped for max_grad_norm, -] on the device, two copies used alternately (the update kernel
         # reads one and writes the other: include/vit4hep_hip.h, v4h_adamw_step_sched)
         st = getattr(self, "_state", None)
@@ -262,6 +269,8 @@ class CFMTrainer:
     def step(self, x, c, t=None, x0=None):
         """One BaseExperiment._step.  Returns (loss, grad_norm) as 0-dim device tensors (pre-clip norm, like clip_grad_norm_)."""
         with _lib.on_device(self.flat_p):
+            if self.max_steps_ahead > 0 and not getattr(self, "_in_capture", False):
+                self._throttle()
             if self.use_graph and t is None and x0 is None and self.max_grad_norm is None and not collectives_enabled():
                 return self._step_graphed(x, c)
             return self._step(x, c, t, x0)
@@ -352,6 +361,15 @@ class CFMTrainer:
         if not capturing and self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
             self.raise_if_nonfinite()
         return out_loss, self.gnorm
+
+    def _throttle(self):
+        """Keep the host at most ``max_steps_ahead`` update steps ahead of the device (see __init__)."""
+        ring = self._ahead_events
+        if len(ring) >= self.max_steps_ahead:
+            ring.pop(0).synchronize()
+        ev = torch.cuda.Event()
+        ev.record()
+        ring.append(ev)
 
     def finish(self):
         """Order a pipelined update (pipeline_update) into the current stream: call before parameters, moments or gradients are read by anything but the
