@@ -400,8 +400,7 @@ def cpu_baseline(w, budget_s=16.0):
     else:
         cfg = O.ViTConfig(shape=w["shape"], patch_shape=(), depth=depth, condition_dim=w["cond"], segments=tuple(w["segments"]))
     # the GPU box gives one GPU's share of the host: 16 cores (its os.cpu_count() reports the whole machine)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = int(os.environ.get("V4H_CPU_THREADS", min(avail, 16)))
+    threads = int(os.environ.get("V4H_CPU_THREADS", min(cpu_share(), 16)))
     torch.set_num_threads(threads)
     p = O.golden_fill(cfg)
     st = O.AdamWState()
@@ -430,7 +429,38 @@ def cpu_baseline(w, budget_s=16.0):
     return rec
 
 
+def cgroup_cpu_stat():
+    for pth in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        if os.path.exists(pth):
+            return {ln.split()[0]: int(ln.split()[1]) for ln in open(pth)}
+    return {}
+
+
+def cpu_share():
+    """CPUs this process may really use: the container's CFS quota (cgroup cpu.max / cfs_quota_us) when there is one, else its affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                n = min(n, max(1, int(q) // int(per)))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
+    # The GPU box shows 256 CPUs and grants 16 (CFS quota): left alone, PyTorch sizes its intra-op pool to 128 threads, the host-side set-up of this
+    # script (parameter init, synthetic batch) burns the quota of several periods at once, and the kernel then freezes the WHOLE process for 40-70 ms
+    # some periods later - measured inside the timed region, one step() call of 1 ms taking 45 ms with the device idle (profiles/r04_notes.md, section 6).
+    # A rank uses the share it has (its part of it when several ranks run on the node).
+    share = max(1, cpu_share() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))))
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), share)))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -497,14 +527,19 @@ def main():
         loss, gn = trainer.step(x, c)
     sync()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cg0 = cgroup_cpu_stat() if os.environ.get("V4H_BENCH_STEP_EVENTS") == "1" else None
     t0 = time.perf_counter()
     e0.record()
     step_marks = [] if os.environ.get("V4H_BENCH_STEP_EVENTS") == "1" else None  # diagnostic: one event per step (a barrier packet each, ~0.1 %)
+    host_marks = []
+    host_only = os.environ.get("V4H_BENCH_HOST_TIMES") == "1"  # diagnostic: host time of every step() call, nothing added to the stream
     for _ in range(args.steps):
         loss, gn = trainer.step(x, c)
         if step_marks is not None:
             step_marks.append(torch.cuda.Event(enable_timing=True))
             step_marks[-1].record()
+        if step_marks is not None or host_only:
+            host_marks.append(time.perf_counter())
     trainer.finish()  # (a pipelined update of the last step is ordered into the timed stream: both clocks below include it)
     e1.record()
     sync()
@@ -513,7 +548,19 @@ def main():
     if step_marks:
         ts = [e0.elapsed_time(m) for m in step_marks]
         per = [round(b - a, 3) for a, b in zip([0.0] + ts[:-1], ts)]
-        print(f"bench.py: device ms per step (rank {rank}): {per}", file=sys.stderr)
+        print(f"bench.py: device ms per step (rank {rank}): {per[:64]}", file=sys.stderr)
+        print(f"bench.py: device steps over 6 ms (index, ms): {[(i, v) for i, v in enumerate(per[:-1]) if v > 6.0]}", file=sys.stderr)
+        hp = [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_marks[:-1], host_marks)]
+        print(f"bench.py: host ms per step() call (rank {rank}): {hp[:64]}", file=sys.stderr)
+        print(f"bench.py: host calls over 10 ms (index, ms since the start of the timed region, ms): {[(i, round((host_marks[i] - t0) * 1e3, 1), v) for i, v in enumerate(hp) if v > 10.0]}",
+              file=sys.stderr)
+        cg1 = cgroup_cpu_stat()
+        print(f"bench.py: container cpu.stat over the timed region: {({k: cg1[k] - cg0[k] for k in cg0 if cg1.get(k) != cg0[k]})}; torch threads {torch.get_num_threads()}",
+              file=sys.stderr)
+    if host_only:
+        hp = [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_marks[:-1], host_marks)]
+        print(f"bench.py: host calls over 10 ms (index, ms since the start of the timed region, ms): {[(i, round((host_marks[i] - t0) * 1e3, 1), v) for i, v in enumerate(hp) if v > 10.0]}",
+              file=sys.stderr)
     CFMTrainer.check_finite(gn)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     rank_walls = None
