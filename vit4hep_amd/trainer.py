@@ -365,9 +365,12 @@ class CFMTrainer:
     def _throttle(self):
         """Keep the host at most ``max_steps_ahead`` update steps ahead of the device (see __init__)."""
         ring = self._ahead_events
+        ev = None
         if len(ring) >= self.max_steps_ahead:
-            ring.pop(0).synchronize()
-        ev = torch.cuda.Event()
+            ev = ring.pop(0)
+            ev.synchronize()
+        if ev is None:
+            ev = torch.cuda.Event()  # (the ring's events are re-used: no event is created after the first max_steps_ahead steps)
         ev.record()
         ring.append(ev)
 
