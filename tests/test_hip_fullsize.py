@@ -155,3 +155,9 @@ def test_ragged_batch_sizes_match_the_oracle(batch, mode):
     contractions (csrc/v4h_gemm.hip: pick_mlp_tile) and the contraction kernel itself (ring kernel from 2048 rows on) change with it, the weight
     gradients' K splits get ragged tails.  ds2 shape model, depth 2; every gradient tensor against the oracle."""
     _compare_with_oracle(O.ds2(2), batch, mode, 50 + batch)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 7])
+def test_ragged_batch_sizes_of_the_long_sequence_model_match_the_oracle(batch):
+    """ds3 shape model (450 tokens of 90: the whole-item-image attention kernels), depth 2, odd batch sizes; every gradient tensor against the oracle."""
+    _compare_with_oracle(O.ds3(2), batch, "bf16", 70 + batch)

@@ -11,6 +11,7 @@ import torch
 
 from oracle import vit_cfm_oracle as O
 from tests import hiputil as U
+from vit4hep_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -475,3 +476,47 @@ def test_bounded_host_run_ahead_changes_nothing():
     for other in out[1:]:
         for (l0, g0), (l1, g1) in zip(out[0], other):
             assert abs(l0 - l1) <= 2e-6 * abs(l0) and abs(g0 - g1) <= 2e-5 * abs(g0)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_written_gradients_stage_by_stage_equal_the_whole_pass(mode):
+    """Gradient mode 1 with the backward issued one stage per call (each call zeroes and writes only its own stage's tensors; the adaLN gradients are then
+    per-block launches instead of the whole pass's grouped contraction): every tensor equals the single-call pass on a poisoned buffer."""
+    from vit4hep_amd.autograd import run_backward, run_forward
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    x, c, noise = _data(cfg, 4, 71, 1)
+    t, x0 = noise[0]
+    model = U.build_models(cfg, mode, O.golden_fill(cfg))
+    tr = CFMTrainer(model, iterations=40)
+    lib = _lib.load()
+    plan_h = tr.net._get_plan().handle
+    xt = (1 - t.view(-1, 1, 1, 1, 1)) * x0 + t.view(-1, 1, 1, 1, 1) * x
+    nst = len(tr.stage_slices)
+    res = []
+    for staged in (False, True):
+        with torch.no_grad():
+            v, ws = run_forward(tr.net, tr.p_views, xt, t.reshape(-1), c, True)
+            dv = torch.full_like(v, 1e-3)
+            tr.flat_g.fill_(float("nan"))
+            pad = torch.ones_like(tr.flat_g, dtype=torch.bool)
+            for lo, p in zip(tr.offsets, tr.params):
+                pad[lo : lo + p.numel()] = False
+            tr.flat_g[pad] = 0.0
+            _lib.check(lib.v4h_plan_set_gradient_mode(plan_h, 1), "mode")
+            try:
+                if staged:
+                    for st in range(nst):
+                        run_backward(tr.net, tr.p_views, tr.g_views, dv, ws, st, st)
+                else:
+                    run_backward(tr.net, tr.p_views, tr.g_views, dv, ws, 0, nst - 1)
+            finally:
+                lib.v4h_plan_set_gradient_mode(plan_h, 0)
+            torch.cuda.synchronize()
+            res.append(tr.flat_g.clone())
+    assert torch.isfinite(res[0]).all() and torch.isfinite(res[1]).all()
+    names = {p.data_ptr(): n for n, p in model.named_parameters()}
+    for lo, p in zip(tr.offsets, tr.params):
+        a, b = res[0][lo : lo + p.numel()], res[1][lo : lo + p.numel()]
+        assert U.rms_err(b, a) < (1e-5 if mode == "f32" else 2e-3), names.get(p.data_ptr())
