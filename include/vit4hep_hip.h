@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define V4H_ABI_VERSION 10
+#define V4H_ABI_VERSION 11
 
 /* arithmetic mode of the contractions */
 #define V4H_MODE_F32 0  /* exact f32 MFMA (v_mfma_f32_16x16x4_f32), f32 activations: parity mode (<= 1e-4 rel) */
@@ -128,6 +128,15 @@ int32_t v4h_plan_join(const v4h_plan* plan, void* stream);
  * into with atomics are zeroed by the call itself, in the launch that zeroes its workspace accumulators anyway: an update loop that owns its gradient
  * buffer (vit4hep_amd/trainer.py) drops its zero fill of all gradients (104 MB per step at ds2).  Same values either way (bitwise for the weights). */
 int32_t v4h_plan_set_gradient_mode(const v4h_plan* plan, int32_t mode);
+/* Storage of the residual stream inside the workspace (ABI 11).  The reference keeps x of nn/vit.py:327-333 and its gradient in f32 because everything
+ * there is f32; in V4H_MODE_BF16 every other activation of this library is already bf16 and the two f32 streams were 24 % of the step's HBM bytes for
+ * no FLOPs.  x_bf16 != 0: the saved LayerNorm inputs (x before each block, x between a block's two branches) are stored as bf16; dx_bf16 != 0: the
+ * gradient handed from one LayerNorm backward to the next is.  All arithmetic on them (gated update, row statistics, the sums of the backward) stays
+ * f32 in registers.  Call BEFORE sizing the workspace (v4h_plan_workspace_bytes changes) and keep it fixed between a forward and its backward.
+ * V4H_MODE_F32 plans and widths the 16-byte LayerNorm kernels do not serve (hidden_dim % 8 != 0 or > 512) refuse a non-zero request.  Default: 0, 0. */
+int32_t v4h_plan_set_residual_storage(const v4h_plan* plan, int32_t x_bf16, int32_t dx_bf16);
+/* bit 0: x is stored as bf16, bit 1: dx is */
+int32_t v4h_plan_residual_storage(const v4h_plan* plan);
 /* Backward of the forward that last filled d_workspace (training != 0).  d_dout (B,1,L,A,R) f32.
  * d_grads: host array of device pointers to f32 gradient tensors, same order/shapes as d_params; gradients are
  * ACCUMULATED into them (zero them first for a fresh gradient).  Stages allow overlap of the gradient all-reduce

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/vit4hep_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 10
+    assert _lib.load().v4h_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_product_library_contains_no_ablation_kernels_and_refuses_to_select_one():

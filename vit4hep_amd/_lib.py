@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # VIT4HEP_AMD_LIB: load another build of the same ABI (same-box A/B measurements of kernel changes)
 LIB_PATH = os.environ.get("VIT4HEP_AMD_LIB") or os.path.join(HERE, "libvit4hep_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MODE_F32 = 0
 MODE_BF16 = 1
 MODES = {"f32": MODE_F32, "fp32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16}
@@ -67,6 +67,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, _vp]),
     "v4h_plan_join": (_i32, [_vp, _vp]),
     "v4h_plan_set_gradient_mode": (_i32, [_vp, _i32]),
+    "v4h_plan_set_residual_storage": (_i32, [_vp, _i32, _i32]),
+    "v4h_plan_residual_storage": (_i32, [_vp]),
     "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_backward_events": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _vp, _vp, _vp, _pp]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),
@@ -202,7 +204,7 @@ class Plan:
     ignored); forward / backward calls then need the index map and position table (include/vit4hep_hip.h)."""
 
     def __init__(self, shape, patch_shape, condition_dim, hidden_dim, depth, num_heads, mlp_hidden, freq_dim=256, mode="f32", in_channels=1, mapped=None,
-                 x_embed_in=0, c_embed_in=0):
+                 x_embed_in=0, c_embed_in=0, residual="f32"):
         lib = load()
         cfg = V4HConfig()
         cfg.shape[:] = [int(v) for v in (shape if mapped is None else (0, 0, 0))]
@@ -227,6 +229,12 @@ class Plan:
             tokens, patch_dim, voxels = (int(v) for v in mapped)
             check(lib.v4h_plan_create_mapped(C.byref(cfg), tokens, patch_dim, voxels, C.byref(h)), "v4h_plan_create_mapped")
         self.handle = h
+        # storage of the residual stream and of its gradient inside the workspace (include/vit4hep_hip.h: v4h_plan_set_residual_storage)
+        if residual not in RESIDUAL:
+            raise ValueError(f"residual storage must be one of {sorted(RESIDUAL)}, got {residual!r}")
+        self.residual = residual
+        if residual != "f32":
+            check(lib.v4h_plan_set_residual_storage(h, *RESIDUAL[residual]), "v4h_plan_set_residual_storage")
         self.num_params = lib.v4h_plan_num_params(h)
         self.num_stages = lib.v4h_vit_num_backward_stages(h)
         self.shapes = []
@@ -246,6 +254,7 @@ class Plan:
             pass
 
 
+RESIDUAL = {"f32": (0, 0), "bf16": (1, 1), "x_bf16": (1, 0), "dx_bf16": (0, 1)}  # (x stored as bf16, dx stored as bf16)
 FWD_TRAINING, FWD_REUSE_OPERANDS, FWD_SAME_CONDITION, ENERGY_SAME_CONDITION, ENERGY_COMPOSED = 1, 2, 4, 4, 8  # flag bits of include/vit4hep_hip.h
 
 

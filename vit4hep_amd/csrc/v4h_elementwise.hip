@@ -374,8 +374,8 @@ template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_boun
         gy[q][n] = xh[q][n] = dxi[q][n] = yv[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D && ok[q]) {
           gy[q][n] = load4(du + row[q] * D + c);  // holds du for now
-          xh[q][n] = load4(a.x + row[q] * D + c);  // holds x for now
-          if (a.dx_in) dxi[q][n] = load4(a.dx_in + row[q] * D + c);
+          xh[q][n] = load4(reinterpret_cast<const float*>(a.x) + row[q] * D + c);  // holds x for now
+          if (a.dx_in) dxi[q][n] = load4(reinterpret_cast<const float*>(a.dx_in) + row[q] * D + c);
           if (y) yv[q][n] = load4(y + row[q] * D + c);
         }
       }
@@ -415,7 +415,7 @@ template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_boun
 #pragma unroll
           for (int r = 0; r < 4; ++r) dx[r] = rs[q] * (gy[q][n][r] - s1[q] - xh[q][n][r] * s2[q]);
           dx += dxi[q][n];
-          if (a.dx_out) store4(a.dx_out + row[q] * D + c, dx);
+          if (a.dx_out) store4(reinterpret_cast<float*>(a.dx_out) + row[q] * D + c, dx);
           if (a.dx_out_t) store4(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
           if (y) {
             acc_g[n] += dx * yv[q][n];
@@ -454,16 +454,19 @@ template <typename T, int LN_MAXV, int LNB_ROWS, int R> __global__ __launch_boun
 // 16-byte rate (MI355X_MICROARCH.md).  D = 480: 60 of 64 lanes active, one group per lane.
 // With `y` given the kernel first applies the gated residual update of the branch above (nn/vit.py:331-332): x = x + gate[b] * y, written to
 // x_out - the contraction that produced y then has a plain-store epilogue instead of reading and rewriting the f32 residual stream.
-template <typename T, int NV8> __global__ __launch_bounds__(256) void ln_modulate_fwd8_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+// XT: storage type of the residual stream (x, x_out): float, or - round 5, bf16 mode - bf16: the row is then read and written in 2 instead of 4 bytes
+// per element (12 -> 8 bytes per element and launch).  The update x + gate * y, the statistics and u are computed from the f32 sum in registers; only
+// what is handed to the next kernel is rounded.
+template <typename T, typename XT, int NV8> __global__ __launch_bounds__(256) void ln_modulate_fwd8_kernel(const XT* __restrict__ x, const float* __restrict__ shift,
                                                                                   const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
                                                                                   float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn, int D,
                                                                                   const T* __restrict__ y, const float* __restrict__ gate, int ld_gate,
-                                                                                  float* __restrict__ x_out) {
+                                                                                  XT* __restrict__ x_out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
   const int b = row / Tn;
-  const float* xr = x + (long)row * D;
+  const XT* xr = x + (long)row * D;
   f32x8 v[NV8];
   float s = 0.f;
 #pragma unroll
@@ -552,8 +555,8 @@ template <typename T, int NV8, int LNB_ROWS, int R> __global__ __launch_bounds__
         for (int r = 0; r < 8; ++r) gy[q][n].v[r] = xh[q][n].v[r] = dxi[q][n].v[r] = yv[q][n].v[r] = 0.f;
         if (c < D && ok[q]) {
           gy[q][n] = load8(du + row[q] * D + c);   // holds du for now
-          xh[q][n] = load8(a.x + row[q] * D + c);  // holds x for now
-          if (a.dx_in) dxi[q][n] = load8(a.dx_in + row[q] * D + c);
+          xh[q][n] = load8(reinterpret_cast<const float*>(a.x) + row[q] * D + c);  // holds x for now
+          if (a.dx_in) dxi[q][n] = load8(reinterpret_cast<const float*>(a.dx_in) + row[q] * D + c);
           if (y) yv[q][n] = load8(y + row[q] * D + c);
         }
       }
@@ -596,7 +599,7 @@ template <typename T, int NV8, int LNB_ROWS, int R> __global__ __launch_bounds__
             acc_g[n].v[r] += dx.v[r] * yv[q][n].v[r];
             dyv.v[r] = dx.v[r] * gt[n].v[r];
           }
-          if (a.dx_out) store8(a.dx_out + row[q] * D + c, dx);
+          if (a.dx_out) store8(reinterpret_cast<float*>(a.dx_out) + row[q] * D + c, dx);
           if (a.dx_out_t) store8(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
           if (y) store8(reinterpret_cast<T*>(a.dy) + row[q] * D + c, dyv);
         }
@@ -665,76 +668,10 @@ template <> struct Raw8<float> {
   }
 };
 
-template <typename T, int NV8, bool RESID> __global__ __launch_bounds__(256) void ln_modulate_fwd8v2_kernel(const float* __restrict__ x, const float* __restrict__ shift,
-                                                                                                const float* __restrict__ scale, int ld_mod, T* __restrict__ u,
-                                                                                                float* __restrict__ mean, float* __restrict__ rstd, int BT, int Tn,
-                                                                                                int D, const T* __restrict__ y, const float* __restrict__ gate,
-                                                                                                int ld_gate, float* __restrict__ x_out) {
-  const int lane = threadIdx.x & 63;
-  // (a grid of fewer workgroups than rows / 4 walks the rows with a stride: persistent form, A/B hook V4H_LNF_GRID)
-  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < BT; row += gridDim.x * 4) {
-  const int b = row / Tn;
-  Raw8<float> xr[NV8], gr[NV8], shr[NV8], scr[NV8];
-  Raw8<T> yr[NV8];
-#pragma unroll
-  for (int n = 0; n < NV8; ++n) {  // every request of the wave, back to back
-    const int c = lane * 8 + 512 * n, cl = c < D ? c : 0;
-    xr[n].ld(x + (long)row * D + cl);
-    if (RESID) {
-      yr[n].ld(y + (long)row * D + cl);
-      gr[n].ld(gate + (long)b * ld_gate + cl);
-    }
-    shr[n].ld(shift + (long)b * ld_mod + cl);
-    scr[n].ld(scale + (long)b * ld_mod + cl);
-  }
-  __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks some of the requests below the first reduction to save registers)
-  f32x8 v[NV8];
-  float s = 0.f;
-#pragma unroll
-  for (int n = 0; n < NV8; ++n) {
-    const float m = lane * 8 + 512 * n < D ? 1.0f : 0.0f;
-    v[n] = xr[n].cvt(m);
-    if (RESID) {
-      const f32x8 yv = yr[n].cvt(m), gv = gr[n].cvt(1.0f);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[n].v[r] += gv.v[r] * yv.v[r];
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) s += v[n].v[r];
-  }
-  const float mu = wave_sum_dpp(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int n = 0; n < NV8; ++n) {
-    const float m = lane * 8 + 512 * n < D ? 1.0f : 0.0f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float d = (v[n].v[r] - mu) * m;
-      q += d * d;
-    }
-  }
-  const float rs = 1.0f / sqrtf(wave_sum_dpp(q) / (float)D + 1e-6f);
-#pragma unroll
-  for (int n = 0; n < NV8; ++n) {
-    const int c = lane * 8 + 512 * n;
-    if (c < D) {
-      const f32x8 sh = shr[n].cvt(1.0f), sc = scr[n].cvt(1.0f);
-      f32x8 o;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o.v[r] = (v[n].v[r] - mu) * rs * (1.0f + sc.v[r]) + sh.v[r];
-      if (RESID) store8(x_out + (long)row * D + c, v[n]);
-      store8(u + (long)row * D + c, o);
-    }
-  }
-  if (lane == 0) {
-    if (mean) mean[row] = mu;
-    if (rstd) rstd[row] = rs;
-  }
-  }
-}
-
 // Backward: NW waves per workgroup, ROWS consecutive tokens of one sample per workgroup, R rows requested at once per wave.
-template <typename T, int NV8, int ROWS, int NW, int R, bool DXIN, bool HASY, bool DXOUT, bool DXOUT_T>
+// XT / GT: storage types of the saved LayerNorm input x and of the residual-stream gradient (dx_in, dx_out): float, or bf16 in bf16 mode (round 5:
+// 18 -> 12 bytes per element and launch).  Every sum - the row statistics, dx_in + the LayerNorm term, the per-sample reductions - is f32 in registers.
+template <typename T, typename XT, typename GT, int NV8, int ROWS, int NW, int R, bool DXIN, bool HASY, bool DXOUT, bool DXOUT_T>
 __global__ __launch_bounds__(64 * NW) void ln_modulate_bwd8v2_kernel(const LnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -757,7 +694,8 @@ __global__ __launch_bounds__(64 * NW) void ln_modulate_bwd8v2_kernel(const LnBwd
     bool ok[R];
     float mu[R], rs[R], s1[R], s2[R];
     Raw8<T> dur[R][NV8], yr[R][NV8];
-    Raw8<float> xr[R][NV8], dir[R][NV8];
+    Raw8<XT> xr[R][NV8];
+    Raw8<GT> dir[R][NV8];
 #pragma unroll
     for (int q = 0; q < R; ++q) {  // every request of the wave's R rows, back to back (rows beyond the tile: the tile's first row, masked below)
       ok[q] = tb + q < t1;
@@ -768,8 +706,8 @@ __global__ __launch_bounds__(64 * NW) void ln_modulate_bwd8v2_kernel(const LnBwd
       for (int n = 0; n < NV8; ++n) {
         const int c = lane * 8 + 512 * n, cl = c < D ? c : 0;
         dur[q][n].ld(du + row[q] * D + cl);
-        xr[q][n].ld(a.x + row[q] * D + cl);
-        if (DXIN) dir[q][n].ld(a.dx_in + row[q] * D + cl);
+        xr[q][n].ld(reinterpret_cast<const XT*>(a.x) + row[q] * D + cl);
+        if (DXIN) dir[q][n].ld(reinterpret_cast<const GT*>(a.dx_in) + row[q] * D + cl);
         if (HASY) yr[q][n].ld(y + row[q] * D + cl);
       }
     }
@@ -821,7 +759,7 @@ __global__ __launch_bounds__(64 * NW) void ln_modulate_bwd8v2_kernel(const LnBwd
           }
         }
         if (c < D && ok[q]) {
-          if (DXOUT) store8(a.dx_out + row[q] * D + c, dx);
+          if (DXOUT) store8(reinterpret_cast<GT*>(a.dx_out) + row[q] * D + c, dx);
           if (DXOUT_T) store8(reinterpret_cast<T*>(a.dx_out_t) + row[q] * D + c, dx);
           if (HASY) store8(reinterpret_cast<T*>(a.dy) + row[q] * D + c, dyv);
         }
@@ -1160,49 +1098,43 @@ int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t 
   V4H_CHECK_LAUNCH("timestep_embed");
   return V4H_OK;
 }
-int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
-                    hipStream_t s) {
+bool ln_resid16_supported(Mode m, int D) { return m == MODE_BF16 && D % 8 == 0 && D <= 512; }
+int ln_modulate_fwd(Mode m, const void* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
+                    hipStream_t s, bool x16) {
   V4H_CHECK_ARG(D % 4 == 0 && D <= 1024, "ln_modulate: hidden_dim %d unsupported (multiple of 4, <= 1024)", D);
   const dim3 grid((BT + 3) / 4);
-  static const bool wide = !(getenv("V4H_LN_WIDE") && getenv("V4H_LN_WIDE")[0] == '0');  // A/B hook
   const bool al = ((uintptr_t)x % 16) == 0 && ((uintptr_t)u % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)scale % 16) == 0 && ld_mod % 4 == 0;
-  if (wide && al && D % 8 == 0) {
-#define V4H_LNF8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)nullptr, (const float*)nullptr, 0, (float*)nullptr)
-    if (D <= 512) { if (m == MODE_BF16) V4H_LNF8(bf16, 1); else V4H_LNF8(float, 1); }
-    else { if (m == MODE_BF16) V4H_LNF8(bf16, 2); else V4H_LNF8(float, 2); }
+  V4H_CHECK_ARG(!x16 || (al && ln_resid16_supported(m, D)), "ln_modulate: a 16-bit residual stream needs bf16 mode, hidden_dim %d a multiple of 8 up to 512 and 16-byte aligned tensors", D);
+  if (al && D % 8 == 0) {
+#define V4H_LNF8(TT, XT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, XT, NV>), grid, dim3(256), 0, s, (const XT*)x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)nullptr, (const float*)nullptr, 0, (XT*)nullptr)
+    if (x16) V4H_LNF8(bf16, bf16, 1);
+    else if (D <= 512) { if (m == MODE_BF16) V4H_LNF8(bf16, float, 1); else V4H_LNF8(float, float, 1); }
+    else { if (m == MODE_BF16) V4H_LNF8(bf16, float, 2); else V4H_LNF8(float, float, 2); }
 #undef V4H_LNF8
   } else if (D <= 512) {
-    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
-    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 2>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 2>), grid, dim3(256), 0, s, (const float*)x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
+    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 2>), grid, dim3(256), 0, s, (const float*)x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
   } else {
-    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 4>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
-    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 4>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
+    if (m == MODE_BF16) hipLaunchKernelGGL((ln_modulate_fwd_kernel<bf16, 4>), grid, dim3(256), 0, s, (const float*)x, shift, scale, ld_mod, (bf16*)u, mean, rstd, BT, T, D);
+    else hipLaunchKernelGGL((ln_modulate_fwd_kernel<float, 4>), grid, dim3(256), 0, s, (const float*)x, shift, scale, ld_mod, (float*)u, mean, rstd, BT, T, D);
   }
   V4H_CHECK_LAUNCH("ln_modulate_fwd");
   return V4H_OK;
 }
 bool ln_resid_supported(int D) { return D % 8 == 0 && D <= 1024; }
 // x_out = x + gate[b] * y, then LayerNorm + modulate of x_out (the wide kernel only: D % 8 == 0, 16-byte aligned tensors)
-int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* gate, int ld_gate, float* x_out, const float* shift, const float* scale, int ld_mod,
-                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s) {
+int ln_resid_modulate_fwd(Mode m, const void* x, const void* y, const float* gate, int ld_gate, void* x_out, const float* shift, const float* scale, int ld_mod,
+                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s, bool x16) {
   auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
   V4H_CHECK_ARG(ln_resid_supported(D) && y && gate && x_out, "ln_resid_modulate: hidden_dim %d unsupported or null tensor", D);
   V4H_CHECK_ARG(al16(x) && al16(y) && al16(gate) && al16(x_out) && al16(shift) && al16(scale) && al16(u) && ld_gate % 4 == 0 && ld_mod % 4 == 0,
                 "ln_resid_modulate: tensors must be 16-byte aligned");
+  V4H_CHECK_ARG(!x16 || ln_resid16_supported(m, D), "ln_resid_modulate: a 16-bit residual stream needs bf16 mode and hidden_dim %d a multiple of 8 up to 512", D);
   const dim3 grid((BT + 3) / 4);
-  static const bool v2 = getenv("V4H_LNF_V2") && getenv("V4H_LNF_V2")[0] == '1';  // A/B hook: the request-everything-first form (same speed in isolation)
-  static const int pgrid = getenv("V4H_LNF_GRID") ? atoi(getenv("V4H_LNF_GRID")) : 0;
-  const dim3 grid2(pgrid > 0 && pgrid < (BT + 3) / 4 ? pgrid : (BT + 3) / 4);
-#define V4H_LNR8V2(TT) hipLaunchKernelGGL((ln_modulate_fwd8v2_kernel<TT, 1, true>), grid2, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
-  if (v2 && D <= 512) {
-    if (m == MODE_BF16) V4H_LNR8V2(bf16); else V4H_LNR8V2(float);
-    V4H_CHECK_LAUNCH("ln_resid_modulate_fwd");
-    return V4H_OK;
-  }
-#undef V4H_LNR8V2
-#define V4H_LNR8(TT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, NV>), grid, dim3(256), 0, s, x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, x_out)
-  if (D <= 512) { if (m == MODE_BF16) V4H_LNR8(bf16, 1); else V4H_LNR8(float, 1); }
-  else { if (m == MODE_BF16) V4H_LNR8(bf16, 2); else V4H_LNR8(float, 2); }
+#define V4H_LNR8(TT, XT, NV) hipLaunchKernelGGL((ln_modulate_fwd8_kernel<TT, XT, NV>), grid, dim3(256), 0, s, (const XT*)x, shift, scale, ld_mod, (TT*)u, mean, rstd, BT, T, D, (const TT*)y, gate, ld_gate, (XT*)x_out)
+  if (x16) V4H_LNR8(bf16, bf16, 1);
+  else if (D <= 512) { if (m == MODE_BF16) V4H_LNR8(bf16, float, 1); else V4H_LNR8(float, float, 1); }
+  else { if (m == MODE_BF16) V4H_LNR8(bf16, float, 2); else V4H_LNR8(float, float, 2); }
 #undef V4H_LNR8
   V4H_CHECK_LAUNCH("ln_resid_modulate_fwd");
   return V4H_OK;
@@ -1212,43 +1144,39 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   // 16 rows per workgroup, 2 rows in flight per wave: measured best (4 rows in flight or 32-48 rows per workgroup: -1...-6 % end to end)
 #define V4H_LNB_LAUNCH(TT, MAXV) hipLaunchKernelGGL((ln_modulate_bwd_kernel<TT, MAXV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
 #define V4H_LNB8_LAUNCH(TT, NV) hipLaunchKernelGGL((ln_modulate_bwd8_kernel<TT, NV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
-  static const bool wide = !(getenv("V4H_LN_WIDE") && getenv("V4H_LN_WIDE")[0] == '0');  // A/B hook
   auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
   const bool al = al16(a.du) && al16(a.x) && al16(a.dx_in) && al16(a.dx_out) && al16(a.dx_out_t) && al16(a.y) && al16(a.dy) && al16(a.scale) && al16(a.gate) &&
                   a.ld_mod % 4 == 0 && a.ld_mod_gate % 4 == 0;
-  // Round-4 form (options as template parameters, every request of a wave up front): V4H_LNB_V2 = 0 off, else the tile shape
-  // 1: 8 rows / 4 waves / 1 row per wave at a time, 2: 16 / 4 / 2 (the shape of the form above), 3: 24 / 4 / 2, 4: 16 / 8 / 1.
+  // Round-4 form (options as template parameters, every request of a wave up front; 8 rows per workgroup of 4 waves, one row per wave at a time - the
+  // other tile shapes measured slower).  V4H_LNB_V2=0: the round-2 kernel (A/B hook; f32 residual storage only).
   static const int v2 = getenv("V4H_LNB_V2") ? atoi(getenv("V4H_LNB_V2")) : 1;
-  if (v2 > 0 && wide && al && a.D % 8 == 0 && a.D <= 512) {
-    const bool dxin = a.dx_in != nullptr, hasy = a.y != nullptr, dxo = a.dx_out != nullptr, dxt = a.dx_out_t != nullptr;
-    int combo = -1;  // the three combinations the backward pass uses (v4h_runtime.hip); anything else keeps the generic kernel
-    if (!dxin && hasy && dxo && !dxt) combo = 0;        // final layer
-    else if (dxin && hasy && dxo && !dxt) combo = 1;    // inside the stack
-    else if (dxin && !hasy && !dxo && dxt) combo = 2;   // bottom of the stack
-#define V4H_LNB2(TT, ROWS, NW, R, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, 1, ROWS, NW, R, A, B_, C_, D_>), dim3((a.T + ROWS - 1) / ROWS, a.B), dim3(64 * NW), 0, s, a)
-#define V4H_LNB2_COMBO(TT, ROWS, NW, R)                                     \
-  do {                                                                      \
-    if (combo == 0) V4H_LNB2(TT, ROWS, NW, R, false, true, true, false);    \
-    else if (combo == 1) V4H_LNB2(TT, ROWS, NW, R, true, true, true, false); \
-    else V4H_LNB2(TT, ROWS, NW, R, true, false, false, true);               \
+  const bool r16 = a.x16 || a.g16;
+  const bool dxin = a.dx_in != nullptr, hasy = a.y != nullptr, dxo = a.dx_out != nullptr, dxt = a.dx_out_t != nullptr;
+  int combo = -1;  // the three combinations the backward pass uses (v4h_runtime.hip); anything else keeps the generic kernel
+  if (!dxin && hasy && dxo && !dxt) combo = 0;        // final layer
+  else if (dxin && hasy && dxo && !dxt) combo = 1;    // inside the stack
+  else if (dxin && !hasy && !dxo && dxt) combo = 2;   // bottom of the stack
+  V4H_CHECK_ARG(!r16 || (al && combo >= 0 && ln_resid16_supported(m, a.D)),
+                "ln_modulate_bwd: 16-bit residual storage needs bf16 mode, hidden_dim %d a multiple of 8 up to 512, aligned tensors and one of the backward pass's option sets", a.D);
+  if ((v2 > 0 || r16) && al && a.D % 8 == 0 && a.D <= 512 && combo >= 0) {
+#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 8, 4, 1, A, B_, C_, D_>), dim3((a.T + 7) / 8, a.B), dim3(256), 0, s, a)
+#define V4H_LNB2_COMBO(TT, XT, GT)                                     \
+  do {                                                                 \
+    if (combo == 0) V4H_LNB2(TT, XT, GT, false, true, true, false);    \
+    else if (combo == 1) V4H_LNB2(TT, XT, GT, true, true, true, false); \
+    else V4H_LNB2(TT, XT, GT, true, false, false, true);               \
   } while (0)
-#define V4H_LNB2_SHAPE(TT)                                   \
-  do {                                                       \
-    if (v2 == 2) V4H_LNB2_COMBO(TT, 16, 4, 2);               \
-    else if (v2 == 3) V4H_LNB2_COMBO(TT, 24, 4, 2);          \
-    else if (v2 == 4) V4H_LNB2_COMBO(TT, 16, 8, 1);          \
-    else V4H_LNB2_COMBO(TT, 8, 4, 1);                        \
-  } while (0)
-    if (combo >= 0) {
-      if (m == MODE_BF16) V4H_LNB2_SHAPE(bf16); else V4H_LNB2_SHAPE(float);
-      V4H_CHECK_LAUNCH("ln_modulate_bwd");
-      return V4H_OK;
-    }
-#undef V4H_LNB2_SHAPE
+    if (m != MODE_BF16) V4H_LNB2_COMBO(float, float, float);
+    else if (a.x16 && a.g16) V4H_LNB2_COMBO(bf16, bf16, bf16);
+    else if (a.x16) V4H_LNB2_COMBO(bf16, bf16, float);
+    else if (a.g16) V4H_LNB2_COMBO(bf16, float, bf16);
+    else V4H_LNB2_COMBO(bf16, float, float);
+    V4H_CHECK_LAUNCH("ln_modulate_bwd");
+    return V4H_OK;
 #undef V4H_LNB2_COMBO
 #undef V4H_LNB2
   }
-  if (wide && al && a.D % 8 == 0) {
+  if (al && a.D % 8 == 0) {
     if (a.D <= 512) { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 1); else V4H_LNB8_LAUNCH(float, 1); }
     else { if (m == MODE_BF16) V4H_LNB8_LAUNCH(bf16, 2); else V4H_LNB8_LAUNCH(float, 2); }
   } else if (a.D <= 512) {

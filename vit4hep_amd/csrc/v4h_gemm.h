@@ -25,7 +25,7 @@ enum : int {
   EPI_STORE_F32,      // out(f32)[i][j] = acc + bias[j]
   EPI_SILU,           // out(TO) = silu(acc + bias) ; out2(f32) = acc + bias (pre-activation, if out2)
   EPI_COND_SUM,       // s = acc + bias + (resid? resid[i][j] : 0) ; out(f32) = s ; out2(TO) = silu(s)
-  EPI_EMBED,          // out(f32) = acc + bias + rowvec[(i % T)][j]                (x_embedder + pos-emb)
+  EPI_EMBED,          // out(f32, or TO with out_t) = acc + bias + rowvec[(i % T)][j]   (x_embedder + pos-emb)
   EPI_GATE_RESID,     // y = acc + bias ; out2(TO) = y ; out(f32) = resid + gate[b(i)][j] * y
   EPI_GELU,           // pre = acc + bias ; out(TO) = gelu_tanh'(pre) ; out2(TO) = gelu_tanh(pre)   (one tanh serves both)
   EPI_DGELU,          // out(TO) = acc * aux(TO)[i][j]        (aux = gelu_tanh'(pre) saved by the forward)
@@ -66,6 +66,7 @@ struct EpiArgs {
   // EPI_ATOMIC_F32 without K splits: every output element has exactly one writer - `store` makes it a plain store (the output need not be zeroed, and
   // the 35 MB of adaLN weight gradients leave the chip at the store rate instead of the float-atomic rate).  Column sums stay atomic.
   int store;
+  int out_t;  // EPI_EMBED: `out` is TO-typed instead of f32 (the residual stream kept in the mode type, round 5)
 };
 
 struct GemmArgs {
@@ -211,7 +212,8 @@ template <int EPI, typename T, typename TO> struct Epilogue {
       for (int r = 0; r < 8; ++r) v.v[r] = silu_f(v.v[r]);
       store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
     } else if constexpr (EPI == EPI_EMBED) {
-      store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, add8(v, o.a));
+      if (e.out_t) store8(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, add8(v, o.a));
+      else store8(reinterpret_cast<float*>(e.out) + (size_t)i * e.ldo + j, add8(v, o.a));
     } else if constexpr (EPI == EPI_GATE_RESID) {
       if (e.out2) store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
       f32x8 x = o.b;

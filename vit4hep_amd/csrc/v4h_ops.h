@@ -46,21 +46,25 @@ int pos_embed_fwd(const float* freqs, float* pe, const PatchGeom& g, int D, hipS
 int pos_embed_bwd(Mode m, const void* dx0, const float* freqs, float* dfreqs, float* scratch, int B, const PatchGeom& g, int D, hipStream_t s);
 int timestep_embed(Mode m, const float* t, void* out, int B, int F, hipStream_t s);
 
-int ln_modulate_fwd(Mode m, const float* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
-                    hipStream_t s);
+// Storage of the residual stream x (and of its gradient d x): f32, or - bf16 mode only, round 5 - the mode type.  The LayerNorm kernels are the only
+// readers / writers of both besides the embedding epilogue; their statistics, the gated update and every sum stay f32 in registers.
+//   x16:  x, x_out (forward), LnBwdArgs::x are mode-typed     g16: LnBwdArgs::dx_in, dx_out are mode-typed
+bool ln_resid16_supported(Mode m, int D);  // can the 16-bit residual forms serve this width?  (bf16 mode, D % 8 == 0, D <= 512)
+int ln_modulate_fwd(Mode m, const void* x, const float* shift, const float* scale, int ld_mod, void* u, float* mean, float* rstd, int BT, int T, int D,
+                    hipStream_t s, bool x16 = false);
 bool ln_resid_supported(int D);
 // x_out = x + gate[b] * y (gated residual of the branch above, nn/vit.py:331-332), then LayerNorm + modulate of x_out
-int ln_resid_modulate_fwd(Mode m, const float* x, const void* y, const float* gate, int ld_gate, float* x_out, const float* shift, const float* scale, int ld_mod,
-                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s);
+int ln_resid_modulate_fwd(Mode m, const void* x, const void* y, const float* gate, int ld_gate, void* x_out, const float* shift, const float* scale, int ld_mod,
+                          void* u, float* mean, float* rstd, int BT, int T, int D, hipStream_t s, bool x16 = false);
 struct LnBwdArgs {
   // LayerNorm+modulate backward (reference nn/vit.py:309-311,331-332,457-458)
   const void* du;       // [BT][D] mode type: grad wrt the modulated output
-  const float* x;       // [BT][D] LayerNorm input
+  const void* x;        // [BT][D] LayerNorm input (f32, or mode type with x16)
   const float* mean; const float* rstd;
   const float* scale;   // mod chunk, row stride ld_mod
   int ld_mod;
-  const float* dx_in;   // residual-stream grad to add (may be null)
-  float* dx_out;        // f32 (may be null when only dx_out_t is wanted)
+  const void* dx_in;    // residual-stream grad to add (may be null); f32, or mode type with g16
+  void* dx_out;         // f32 / mode type with g16 (may be null when only dx_out_t is wanted)
   void* dx_out_t;       // optional copy in mode type
   float* dshift; float* dscale; int ld_dmod;   // f32 atomics, [B][ld_dmod] chunks
   // fused gate backward of the branch below (nn/vit.py:331-332): dy = gate * dx_out ; dgate += sum_t dx_out * y
@@ -70,6 +74,7 @@ struct LnBwdArgs {
   void* dy;             // [BT][D] mode type
   float* dgate; int ld_dgate;
   int B, T, D;
+  int x16, g16;         // storage of x / of dx_in, dx_out: 0 = f32, 1 = mode type (ln_resid16_supported)
 };
 int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s);
 int silu_bwd(Mode m, const float* dsilu, const float* pre, void* out, int n, hipStream_t s);  // out = dsilu * silu'(pre)

@@ -63,6 +63,7 @@ struct v4h_plan {
   mutable int evi = 0;
   mutable bool side_ok = false;
   mutable bool grad_overwrite = false;  // v4h_plan_set_gradient_mode: backward passes WRITE every gradient of their stages (caller need not zero)
+  mutable bool x16 = false, g16 = false;  // v4h_plan_set_residual_storage: the residual stream / its gradient are kept in the mode type (bf16 mode)
   mutable int device = -1;  // device the side stream and events were created on (first forward / backward call)
 };
 
@@ -248,7 +249,8 @@ extern "C" int32_t v4h_vit_num_backward_stages(const v4h_plan* p) { return p ? p
 
 // ------------------------------------------------------------------------------------------------ workspace layout
 struct BlockWS {
-  float *mean1, *rstd1, *mean2, *rstd2, *lse, *x_mid;
+  float *mean1, *rstd1, *mean2, *rstd2, *lse;
+  char *x_mid;  // residual stream between the two branches: f32, or the mode type (plan.x16)
   char *u1, *qkv, *o, *y1, *u2, *hgrad, *h, *y2;
 };
 struct WS {
@@ -260,7 +262,8 @@ struct WS {
   float *pe, *ht_pre, *hc_pre, *cond, *cemb, *modf, *meanf, *rstdf;
   float *mod_all, *adaB;   // every adaLN modulation of the step in one table (B x ldmod); concatenated adaLN biases
   char* adaW;              // concatenated operand copies of the adaLN weights (ldmod x D), bf16 mode: one contraction makes the whole table
-  std::vector<float*> mod, X;
+  std::vector<float*> mod;
+  std::vector<char*> X;  // residual stream in front of block i (X[depth]: in front of the final layer): f32, or the mode type (plan.x16)
   std::vector<BlockWS> blk;
   // backward
   char* zero_begin; size_t zero_bytes;
@@ -269,7 +272,8 @@ struct WS {
   float* dmod_base;
   float** gtab;  // device table of the grouped adaLN weight-gradient contraction
   float *dsilu, *gxw, *gc0w, *glin, *glinb;
-  float *dxA, *dxB, *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
+  char *dxA, *dxB;  // residual-stream gradient ping-pong: f32, or the mode type (plan.g16)
+  float *delta, *G, *slab[2];  // slab[0]: main stream, slab[1]: side stream
   char *dy[2], *dy2[2], *dhpre[2], *dqkv[2];
   char *dvp, *du, *dof, *dmod_t, *dcond, *dh_small, *dh_small2, *dx0_t;  // dy: gradient entering the MLP half of a block, dy2: the attention half
   size_t total;
@@ -340,8 +344,9 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
   w.modf = w.mod_all ? w.mod_all + (size_t)p.depth * 6 * D : nullptr;
   const int nx = training ? p.depth + 1 : 2;
   w.X.resize(p.depth + 1);
-  std::vector<float*> xs(nx);
-  for (int i = 0; i < nx; ++i) xs[i] = (float*)take(BT * D * 4);
+  const size_t xs_ = p.x16 ? es : 4, gs_ = p.g16 ? es : 4;  // element size of the residual stream / of its gradient
+  std::vector<char*> xs(nx);
+  for (int i = 0; i < nx; ++i) xs[i] = take(BT * D * xs_);
   for (int i = 0; i <= p.depth; ++i) w.X[i] = xs[training ? i : (i & 1)];
   const int nb = training ? p.depth : 1;
   std::vector<BlockWS> bs(nb);
@@ -350,7 +355,7 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     b.mean1 = (float*)take(BT * 4); b.rstd1 = (float*)take(BT * 4);
     b.mean2 = (float*)take(BT * 4); b.rstd2 = (float*)take(BT * 4);
     b.lse = (float*)take((size_t)B * p.H * p.T * 4);
-    b.x_mid = (float*)take(BT * D * 4);
+    b.x_mid = take(BT * D * xs_);
     b.u1 = take(BT * D * es); b.qkv = take(BT * 3 * D * es); b.o = take(BT * D * es); b.y1 = take(BT * D * es);
     b.u2 = take(BT * D * es); b.hgrad = take(BT * M * es); b.h = take(BT * M * es); b.y2 = take(BT * D * es);
   }
@@ -380,8 +385,8 @@ static void layout(const v4h_plan& p, int B, bool training, char* base, WS& w) {
     w.glinb = (float*)take((size_t)p.Ppad * 4);
     w.G = (float*)take((size_t)p.T * D * 4);  // batch sum of d x0 (positional-table backward): accumulated with atomics
     w.zero_bytes = off - z0;
-    w.dxA = (float*)take(BT * D * 4);
-    w.dxB = (float*)take(BT * D * 4);
+    w.dxA = take(BT * D * gs_);
+    w.dxB = take(BT * D * gs_);
     w.delta = (float*)take((size_t)B * p.H * p.T * 4);
     for (int k = 0; k < 2; ++k) w.slab[k] = (float*)take(slab_bytes(p));
     w.dvp = take(BT * p.Ppad * es);
@@ -605,6 +610,17 @@ extern "C" int32_t v4h_plan_set_gradient_mode(const v4h_plan* p, int32_t mode) {
   p->grad_overwrite = mode == 1;
   return V4H_OK;
 }
+extern "C" int32_t v4h_plan_set_residual_storage(const v4h_plan* p, int32_t x_bf16, int32_t dx_bf16) {
+  V4H_CHECK_ARG(p != nullptr, "plan_set_residual_storage: null plan");
+  if (x_bf16 || dx_bf16) {
+    V4H_CHECK_ARG(ln_resid16_supported(p->mode, p->D) && ln_resid_supported(p->D),
+                  "plan_set_residual_storage: a bf16 residual stream needs V4H_MODE_BF16 and hidden_dim %d a multiple of 8 up to 512", p->D);
+  }
+  p->x16 = x_bf16 != 0;
+  p->g16 = dx_bf16 != 0;
+  return V4H_OK;
+}
+extern "C" int32_t v4h_plan_residual_storage(const v4h_plan* p) { return p ? (p->x16 ? 1 : 0) | (p->g16 ? 2 : 0) : 0; }
 extern "C" int32_t v4h_plan_join(const v4h_plan* p, void* stream) {
   V4H_CHECK_ARG(p != nullptr, "plan_join: null plan");
   if (!p->side_ok) return V4H_OK;
@@ -687,7 +703,7 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   else RUN(pos_embed_fwd(c.pf(P_FREQS), w.pe, p->pg, D, c.s));
   {
     GemmArgs a = gargs(w.xp, p->Pxpad, c.W(P_XW), p->Pxpad, BT, D, p->Pxpad);
-    a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T;
+    a.e.out = w.X[0]; a.e.ldo = D; a.e.bias = c.pf(P_XB); a.e.rowvec = w.pe; a.e.ld_rowvec = D; a.e.T = T; a.e.out_t = p->x16;
     RUN(gemm_fwd(m, EPI_EMBED, a, c.s));
   }
   // 4-8. c_embedder, t_embedder, cond = t_emb + c_emb, silu(cond) (nn/vit.py:197-199).  The condition term does not depend on t: a caller
@@ -734,6 +750,8 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
   // 10. DiT blocks (nn/vit.py:327-333)
   static const bool ln_resid = !(getenv("V4H_LN_RESID") && getenv("V4H_LN_RESID")[0] == '0');  // A/B hook
   const bool fuse_resid = ln_resid && ln_resid_supported(D);
+  const bool x16 = p->x16;
+  V4H_CHECK_ARG(!x16 || fuse_resid, "vit_forward: the bf16 residual stream exists only with the gated update fused into the LayerNorm kernels (V4H_LN_RESID=0 is set)");
   for (int i = 0; i < p->depth; ++i) {
     const BlockWS& b = w.blk[i];
     const float* mod = w.mod[i];
@@ -743,9 +761,9 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     // branch by a streaming kernel instead of by a contraction epilogue (16 us per call there, 8 here).  V4H_LN_RESID=0: the GATE_RESID epilogue.
     if (fuse_resid && i > 0) {
       const BlockWS& pb = w.blk[i - 1];
-      RUN(ln_resid_modulate_fwd(m, pb.x_mid, pb.y2, w.mod[i - 1] + 5 * D, ldm, w.X[i], mod, mod + D, ldm, b.u1, b.mean1, b.rstd1, BT, T, D, c.s));
+      RUN(ln_resid_modulate_fwd(m, pb.x_mid, pb.y2, w.mod[i - 1] + 5 * D, ldm, w.X[i], mod, mod + D, ldm, b.u1, b.mean1, b.rstd1, BT, T, D, c.s, x16));
     } else {
-      RUN(ln_modulate_fwd(m, w.X[i], mod, mod + D, ldm, b.u1, b.mean1, b.rstd1, BT, T, D, c.s));
+      RUN(ln_modulate_fwd(m, w.X[i], mod, mod + D, ldm, b.u1, b.mean1, b.rstd1, BT, T, D, c.s, x16));
     }
     GemmArgs a = gargs(b.u1, D, c.W(p->blk(i, B_QKVW)), D, BT, 3 * D, D);
     a.e.out = b.qkv; a.e.ldo = 3 * D; a.e.bias = c.pf(p->blk(i, B_QKVB));
@@ -755,10 +773,10 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
     if (fuse_resid) {
       a.e.out = b.y1; a.e.ldo = D; a.e.bias = c.pf(p->blk(i, B_PROJB));
       RUN(gemm_fwd(m, EPI_STORE, a, c.s));
-      RUN(ln_resid_modulate_fwd(m, w.X[i], b.y1, mod + 2 * D, ldm, b.x_mid, mod + 3 * D, mod + 4 * D, ldm, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
+      RUN(ln_resid_modulate_fwd(m, w.X[i], b.y1, mod + 2 * D, ldm, b.x_mid, mod + 3 * D, mod + 4 * D, ldm, b.u2, b.mean2, b.rstd2, BT, T, D, c.s, x16));
     } else {
       a.e.out = b.x_mid; a.e.ldo = D; a.e.out2 = training ? b.y1 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_PROJB));
-      a.e.rowvec = mod + 2 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = w.X[i]; a.e.ld_resid = D;
+      a.e.rowvec = mod + 2 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = (const float*)w.X[i]; a.e.ld_resid = D;
       RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
       RUN(ln_modulate_fwd(m, b.x_mid, mod + 3 * D, mod + 4 * D, ldm, b.u2, b.mean2, b.rstd2, BT, T, D, c.s));
     }
@@ -771,16 +789,16 @@ extern "C" int32_t v4h_vit_forward(const v4h_plan* p, int32_t B, const void* con
       RUN(gemm_fwd(m, EPI_STORE, a, c.s));
     } else {
       a.e.out = w.X[i + 1]; a.e.ldo = D; a.e.out2 = training ? b.y2 : nullptr; a.e.ldo2 = D; a.e.bias = c.pf(p->blk(i, B_FC2B));
-      a.e.rowvec = mod + 5 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = b.x_mid; a.e.ld_resid = D;
+      a.e.rowvec = mod + 5 * D; a.e.ld_rowvec = ldm; a.e.T = T; a.e.resid = (const float*)b.x_mid; a.e.ld_resid = D;
       RUN(gemm_fwd(m, EPI_GATE_RESID, a, c.s));
     }
   }
   // 11. FinalLayer (nn/vit.py:347-351) with from_patches fused into the store
   if (fuse_resid && p->depth > 0) {
     const BlockWS& pb = w.blk[p->depth - 1];
-    RUN(ln_resid_modulate_fwd(m, pb.x_mid, pb.y2, w.mod[p->depth - 1] + 5 * D, ldm, w.X[p->depth], w.modf, w.modf + D, ldm, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
+    RUN(ln_resid_modulate_fwd(m, pb.x_mid, pb.y2, w.mod[p->depth - 1] + 5 * D, ldm, w.X[p->depth], w.modf, w.modf + D, ldm, w.uf, w.meanf, w.rstdf, BT, T, D, c.s, x16));
   } else {
-    RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, ldm, w.uf, w.meanf, w.rstdf, BT, T, D, c.s));
+    RUN(ln_modulate_fwd(m, w.X[p->depth], w.modf, w.modf + D, ldm, w.uf, w.meanf, w.rstdf, BT, T, D, c.s, x16));
   }
   {
     GemmArgs a = gargs(w.uf, D, c.W(p->fin(F_LINW)), D, BT, p->Ppad, D);
@@ -897,16 +915,16 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       l.du = w.du; l.x = w.X[depth]; l.mean = w.meanf; l.rstd = w.rstdf; l.scale = w.modf + D; l.ld_mod = p->ldmod();
       l.dx_out = dxbuf(0); l.dshift = dmodf; l.dscale = dmodf + D; l.ld_dmod = lddf;
       l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy[(depth - 1) & 1]; l.dgate = dmod(depth - 1) + 5 * D; l.ld_dgate = ldd;
-      l.B = B; l.T = T; l.D = D;
+      l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
       RUN(ln_modulate_bwd(m, l, c.s));
       if (!batch_ada) RUN(adaln_backward(c, dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
       RUN(stage_done(0, ov0 ? p->side : c.s));  // final-layer gradients: all on the weight-gradient stream
     } else if (st <= depth) {
       const int j = st - 1, i = depth - 1 - j;
       const BlockWS& b = w.blk[i];
-      float* dx_in = dxbuf(2 * j);        // grad wrt X[i+1]
-      float* dx_mid = dxbuf(2 * j + 1);   // grad wrt x_mid
-      float* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
+      char* dx_in = dxbuf(2 * j);        // grad wrt X[i+1]
+      char* dx_mid = dxbuf(2 * j + 1);   // grad wrt x_mid
+      char* dx_out = dxbuf(2 * j + 2);   // grad wrt X[i] (same buffer as dx_in, which is dead by then)
       const bool ov = g_overlap_wgrad;
       hipStream_t ws_ = ov ? p->side : c.s;  // stream of the weight-gradient contractions
       // The four temporaries a block's weight gradients read exist twice; block i uses set i & 1.
@@ -944,7 +962,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       l.du = w.du; l.x = b.x_mid; l.mean = b.mean2; l.rstd = b.rstd2; l.scale = w.mod[i] + 4 * D; l.ld_mod = p->ldmod();
       l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = dmod(i) + 3 * D; l.dscale = dmod(i) + 4 * D; l.ld_dmod = ldd;
       l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = dy2_i; l.dgate = dmod(i) + 2 * D; l.ld_dgate = ldd;
-      l.B = B; l.T = T; l.D = D;
+      l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
       RUN(ln_modulate_bwd(m, l, c.s));
       // --- attention branch (nn/vit.py:425-454,331) ---
       RUN(fork_wgrad(2));  // dy2 ready
@@ -969,7 +987,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       } else {
         l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
       }
-      l.B = B; l.T = T; l.D = D;
+      l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
       RUN(ln_modulate_bwd(m, l, c.s));
       if (!batch_ada) RUN(adaln_backward(c, dmod(i), 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
       RUN(stage_done(st, ws_));  // the block's weight gradients (and, unbatched, its adaLN gradients) are the last thing in the side queue

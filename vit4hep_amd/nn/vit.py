@@ -10,6 +10,9 @@ through one autograd node, backward) inside libvit4hep_hip.so.  There is no PyTo
 Extra, optional ``param`` keys (ignored by the reference, which drops unknown keys):
   ``amd_mode``: "f32" (default; exact-f32 MFMA, matches the reference within 1e-4) or "bf16"
                 (bf16 MFMA, f32 accumulate: throughput mode).  Env VIT4HEP_AMD_MODE overrides.
+  ``amd_residual``: storage of the residual stream x and of its gradient inside the library's workspace: "auto" (default: "bf16" in bf16 mode
+                where the 16-byte LayerNorm kernels serve the width, else "f32"), "f32", "bf16", "x_bf16" (x only), "dx_bf16" (gradient only).
+                Arithmetic on them stays f32 in registers; f32 mode always stores f32.  Env VIT4HEP_AMD_RESIDUAL overrides.
 """
 
 from __future__ import annotations
@@ -151,6 +154,9 @@ class ViT(nn.Module):
         self.amd_mode = os.environ.get("VIT4HEP_AMD_MODE") or (param["amd_mode"] if "amd_mode" in param else "f32")
         if self.amd_mode not in _lib.MODES:
             raise ValueError(f"amd_mode must be one of {sorted(_lib.MODES)}, got {self.amd_mode!r}")
+        self.amd_residual = os.environ.get("VIT4HEP_AMD_RESIDUAL") or (param["amd_residual"] if "amd_residual" in param else "auto")
+        if self.amd_residual != "auto" and self.amd_residual not in _lib.RESIDUAL:
+            raise ValueError(f"amd_residual must be 'auto' or one of {sorted(_lib.RESIDUAL)}, got {self.amd_residual!r}")
 
         # what the HIP path implements = what every shape-CFM config uses
         if not self.learn_pos_embed:
@@ -321,9 +327,13 @@ class ViT(nn.Module):
                 raise ValueError(f"patch map shape {self._patch_map.shape} does not match (num_tokens={T}, patch_dim={P})")
             self._plan_key = key
             shape, patch_shape, mapped = (g[1], g[2], None) if g[0] == "grid" else (None, None, (self.num_tokens, int(self.patch_dim), g[2]))
+            residual = self.amd_residual
+            if residual == "auto":
+                D = int(self.hidden_dim)
+                residual = "bf16" if _lib.MODES[self.amd_mode] == _lib.MODE_BF16 and D % 8 == 0 and D <= 512 else "f32"
             self._plan = _lib.Plan(shape, patch_shape, self.condition_dim, self.hidden_dim, self.depth, self.num_heads,
                                    int(self.hidden_dim * self.mlp_ratio), self.t_embedder.frequency_embedding_size, self.amd_mode, mapped=mapped,
-                                   x_embed_in=self.x_embed_in(), c_embed_in=self.c_embed_in())
+                                   x_embed_in=self.x_embed_in(), c_embed_in=self.c_embed_in(), residual=residual)
             got = [tuple(p.shape) for p in self.parameter_list()]
             if got != self._plan.shapes:
                 raise RuntimeError(f"parameter inventory differs from the library's: {got} vs {self._plan.shapes}")
