@@ -107,7 +107,7 @@ shapes = [("fwd qkv", "fwd", BT, 3 * D, D), ("fwd proj", "fwd", BT, D, D), ("fwd
           ("wgrad fc2", "wgrad", D, M, BT), ("wgrad fc1", "wgrad", M, D, BT), ("wgrad proj", "wgrad", D, D, BT), ("wgrad qkv", "wgrad", 3 * D, D, BT),
           ("fwd fc1 plain", "fwd", BT, M, D), ("dgrad fc2 plain", "dgrad", BT, M, D)]
 only = os.environ.get("ONLY")
-names = {1: "two-wg", 2: "ring"}
+names = {1: "two-wg", 2: "ring", 3: "w-stat", 0: "auto"}
 tot = {k: 0.0 for k in KERNELS}
 for nm, kind, I, J, K in shapes:
     if only and only not in nm:

@@ -108,7 +108,7 @@ SIGNATURES = {
     "v4h_calib_copy": (_i32, [_vp, _vp, _i64, _vp]),
 }
 # contraction kernels selectable through v4h_select_contraction_kernel (all exact)
-KERNEL_AUTO, KERNEL_TWO_WG, KERNEL_RING = 0, 1, 2
+KERNEL_AUTO, KERNEL_TWO_WG, KERNEL_RING, KERNEL_WS = 0, 1, 2, 3
 
 _lib = None
 

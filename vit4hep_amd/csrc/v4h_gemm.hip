@@ -6,6 +6,7 @@
 
 #include "v4h_ops.h"
 #include "v4h_gemm2.h"
+#include "v4h_gemm3.h"
 #include "v4h_gemm_small.h"
 
 namespace v4h {
@@ -19,7 +20,8 @@ static int env_flag(const char* n, int dflt) { const char* e = getenv(n); return
 //   KERNEL_AUTO  the measured winners per contraction class (g_pp below),
 //   KERNEL_TWO_WG  the 128 x 160 two-workgroup kernel everywhere (what f32 mode and every small contraction use anyway),
 //   KERNEL_RING  the ring kernel wherever the shape is eligible.
-enum { KERNEL_AUTO = 0, KERNEL_TWO_WG = 1, KERNEL_RING = 2 };
+//   KERNEL_WS  like KERNEL_AUTO (the weight-stationary kernel of v4h_gemm3.h wherever eligible; KERNEL_TWO_WG and KERNEL_RING never use it).
+enum { KERNEL_AUTO = 0, KERNEL_TWO_WG = 1, KERNEL_RING = 2, KERNEL_WS = 3 };
 int kernel_from_env() {
   const char* e = getenv("V4H_GEMM2");
   if (!e) return KERNEL_AUTO;
@@ -73,6 +75,19 @@ inline bool on_ring(const GemmArgs& a, int klen, int bit) {
   return (g_kernel == KERNEL_RING || (g_pp & bit)) && v2_eligible(a, klen);
 }
 
+// The K = hidden_dim contractions (qkv, attn.proj, fc1 + GELU forward; attn.proj and fc2 x GELU' input gradients) on the weight-stationary kernel:
+// the weight slice of a workgroup lives in registers, only activation rows stream (v4h_gemm3.h).  V4H_GEMM3=0: off (A/B hook).
+int g_ws = env_flag("V4H_GEMM3", 1);
+constexpr int WS_K = 480;
+inline bool on_ws(const GemmArgs& a) {
+  if (g_kernel == KERNEL_TWO_WG || g_kernel == KERNEL_RING) return false;
+  return (g_ws != 0 || g_kernel == KERNEL_WS) && v4h_gemm3_eligible(a, WS_K);
+}
+template <bool QKS, int EPI> int run_ws(const GemmArgs& a, hipStream_t s, const char* name) {
+  if (v4h_gemm3_pick_nt(a.J) == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
+  return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 2>>(a, s, name);
+}
+
 template <typename T, typename TO, bool PKS, bool QKS, int BI, int BJ, int EPI, bool CS = false>
 int run(const GemmArgs& a, int splitk, hipStream_t s, const char* name) {
 #ifdef V4H_ABLATIONS
@@ -98,6 +113,9 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if (epi == EPI_SILU) return v4h_small::smallm_launch<false, EPI_SILU>(a, s, "gemm_small/silu");
       if (epi == EPI_COND_SUM) return v4h_small::smallm_launch<false, EPI_COND_SUM>(a, s, "gemm_small/cond_sum");
     }
+    if (epi == EPI_STORE && on_ws(a)) return run_ws<false, EPI_STORE>(a, s, "gemm3_fwd/store");
+    if (epi == EPI_GELU && on_ws(a) && a.e.out2 != nullptr && a.e.ldo2 % 8 == 0 && ((uintptr_t)a.e.out2 % 16) == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L)
+      return run_ws<false, EPI_GELU>(a, s, "gemm3_fwd/gelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
     if (epi == EPI_GELU && on_ring(a, a.K, a.e.out != nullptr ? 2 : 32) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
   }
@@ -136,6 +154,9 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
 #endif
   if constexpr (sizeof(T) == 2) {
     if (g_small && epi == EPI_DSILU && v4h_small::smallm_eligible(a)) return v4h_small::smallm_launch<true, EPI_DSILU>(a, s, "gemm_small/dsilu");
+    if (epi == EPI_STORE && on_ws(a)) return run_ws<true, EPI_STORE>(a, s, "gemm3_dgrad/store");
+    if (epi == EPI_DGELU && on_ws(a) && a.e.aux != nullptr && a.e.ld_aux % 8 == 0 && ((uintptr_t)a.e.aux % 16) == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L)
+      return run_ws<true, EPI_DGELU>(a, s, "gemm3_dgrad/dgelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 4)) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
     if (epi == EPI_DGELU && on_ring(a, a.K, 8) && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");
   }
@@ -230,8 +251,8 @@ int gemm_wgrad_slab(Mode m, const GemmArgs& a0, int splitk, float* slab, int* nz
 }
 
 int select_contraction_kernel(int which) {
-  if (which != KERNEL_AUTO && which != KERNEL_TWO_WG && which != KERNEL_RING) {
-    v4h_set_error("select_contraction_kernel: %d is not one of 0 (automatic), 1 (two-workgroup kernel), 2 (ring kernel wherever eligible)", which);
+  if (which != KERNEL_AUTO && which != KERNEL_TWO_WG && which != KERNEL_RING && which != KERNEL_WS) {
+    v4h_set_error("select_contraction_kernel: %d is not one of 0 (automatic), 1 (two-workgroup kernel), 2 (ring kernel wherever eligible), 3 (weight-stationary kernel wherever eligible)", which);
     return V4H_ERR_ARG;
   }
   g_kernel = which;

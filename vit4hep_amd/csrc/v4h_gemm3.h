@@ -1,0 +1,315 @@
+// Third-generation bf16 contraction: WEIGHT-STATIONARY, for the Linears whose contraction length is the hidden width (K = 480):
+// qkv, attn.proj and mlp.fc1 (+ GELU) forward, the input gradients of attn.proj and of mlp.fc2 (x GELU')
+// (reference nn/vit.py:416,420,425-454 and timm Mlp :312-322).  Same operand conventions as v4h_gemm.h:
+//
+//     Out[i][j] = sum_k P[i][k] * Q[j][k]      P = activations [tokens][K] (K-contiguous), Q = weight, K-contiguous [J][K] (forward) or K-strided [K][J] (dgrad)
+//
+// Why another kernel.  The ring kernel (v4h_gemm2.h) stages BOTH operands through the CU's global->LDS path: 53 KB per K = 64 step, which that path takes
+// in about the 1280 clocks the matrix pipe needs for the step - and a K = 480 tile is only 7.5 steps long, so fill, drain and whole-tile rounds (qkv: 2.39
+// rounds paid as 3; N = 480: 204 tiles on 256 CUs) are never amortised: 0.20-0.22 of peak where K = 1920 reaches 0.31.  With K = 480 a column slice of the
+// weight is small enough to live in REGISTERS for the whole launch:
+//
+//   * a wave owns NT = 3 (or 2) column tiles of 16 and keeps their fragments for every K = 32 slab in VGPRs: 15 x 3 x 4 = 180 registers (120), loaded once
+//     (forward: straight from global memory in fragment layout; dgrad: the K-strided weight goes through LDS once and is read transposed);
+//     8 waves = one workgroup per CU = 384 (256) columns;
+//   * only ACTIVATION rows stream: 16-row tiles of 15 KB through a 6-slot LDS ring filled by global->LDS DMA five tiles ahead - 15 KB per 16 x 384 x 480
+//     MACs instead of 53 KB per 256 x 160 x 64, i.e. 390 instead of 98 FLOP per staged byte; every wave reads every A fragment (one ds_read_b128 feeds its 3 MFMAs);
+//   * the grid is cut into EQUAL shares: workgroup = (column slice, contiguous range of 16-row tiles), ranges differing by at most one tile - no tile rounds;
+//   * ping-pong without extra registers: the two waves of a SIMD run matrix slot (45 MFMAs + 15 fragment reads) and auxiliary slot (epilogue of the tile
+//     just finished, DMA of the tile five ahead) in opposite order between two barriers, so a SIMD's matrix pipe nearly always has a wave with MFMAs to issue;
+//   * A image [octet of chunks][row half][chunk][row] (tools/lds_model.py conventions): DMA pieces are 8 rows x 128 contiguous bytes, and the 16 lanes of
+//     every ds_read_b128 service group fall on 16 different 16-byte bank groups (derivation in DESIGN.md section 5).
+#pragma once
+#include "v4h_gemm2.h"
+
+template <bool QKS_, int EPI_, int NT_, int KS_ = 15> struct Gemm3Cfg {
+  static constexpr bool QKS = QKS_;
+  static constexpr int EPI = EPI_, NT = NT_, KS = KS_, K = 32 * KS_;
+  static constexpr int NW = 8, NTHR = 512, WJ = 16 * NT_, BJ = NW * WJ;  // columns per wave / per workgroup
+  static constexpr int TILE_BYTES = 16 * K * 2;                          // LDS image of one 16-row tile
+  static constexpr int NI = TILE_BYTES / 1024;                           // DMA instructions (1 KiB each) per tile = KS
+  static constexpr int NREG = 2 * (KS / 2);                              // ... of which regular (8 rows x 8 chunks); KS odd: one more of 16 rows x 4 chunks
+  static constexpr int NPW = (NI + NW - 1) / NW;                         // per wave, at most
+  static constexpr int R = 6;                                            // ring slots (tiles)
+  static constexpr int BIAS_OFF = R * TILE_BYTES;
+  static constexpr int LDS_BYTES = BIAS_OFF + BJ * 4;
+  using ImgQ = ImgKStrided<bf16, BJ, 32, NW>;                             // dgrad prologue: one K = 32 slab of the weight slice, [32][BJ]
+  static constexpr int Q_ROUND = (R * TILE_BYTES) / ImgQ::BYTES;         // slabs staged per prologue round
+  static constexpr int EPI_ST = NT == 3 ? 2 : 1;                         // 16-byte accesses per lane, tile and tensor
+  static constexpr int EPI_OPS = EPI == EPI_STORE ? EPI_ST : 2 * EPI_ST; // vector-memory instructions of one epilogue (GELU: two outputs; DGELU: loads + stores)
+  static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogue not built for the weight-stationary kernel");
+  static_assert(NT == 2 || NT == 3, "column tiles per wave");
+  static_assert(NI == KS && LDS_BYTES <= 160 * 1024 && Q_ROUND >= 1, "ring shape");
+};
+
+template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kernel(const GemmArgs a, int ncs, int nrg, int wpx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < C::NW);
+  const int half = wave >> 2;
+  auto sgpr = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
+  const bf16* gP = reinterpret_cast<const bf16*>(a.P);
+  const bf16* gQ = reinterpret_cast<const bf16*>(a.Q);
+
+  // workgroup -> (column slice, row group).  Blocks are dealt round-robin over the 8 XCDs: block b runs share (b % 8) * wpx + b / 8 of the row-group-major
+  // list, so the workgroups of one XCD are consecutive row groups with ALL their column slices - an activation tile is fetched into that L2 once (speed only).
+  const int share = (int)(blockIdx.x & 7) * wpx + (int)(blockIdx.x >> 3);
+  if (share >= ncs * nrg) return;
+  const int rg = sgpr(share / ncs), cs = share - rg * ncs;
+  const int nrt = (a.I + 15) >> 4;
+  const int t_begin = (int)((long)rg * nrt / nrg), t_end = (int)((long)(rg + 1) * nrt / nrg);
+  const int jw0 = cs * C::BJ + wave * C::WJ;  // this wave's first column
+  const bool active = jw0 < a.J;              // (wave-uniform; J is a whole number of wave slices)
+  const int c = lane & 15, g = lane >> 4;
+
+  // ------------------------------------------------------------------ A ring: request side
+  int t_issue = t_begin, q_issue = 0;
+  auto issue = [&]() -> int {  // this wave's share of the DMA of tile t_issue (into ring slot q_issue); returns the number of instructions issued
+    int n = 0;
+    if (t_issue < t_end) {
+      const int row0 = t_issue * 16;
+      char* dst = smem + q_issue * C::TILE_BYTES;
+#pragma unroll
+      for (int k = 0; k < C::NPW; ++k) {
+        const int inst = wave + k * C::NW;  // (scalar)
+        if (inst < C::NI) {
+          int row, chunk;
+          if (inst < C::NREG) {
+            row = row0 + (inst & 1) * 8 + (lane & 7);
+            chunk = (inst >> 1) * 8 + (lane >> 3);
+          } else {
+            row = row0 + (lane & 15);
+            chunk = (C::KS / 2) * 8 + (lane >> 4);
+          }
+          row = min(row, a.I - 1);  // rows beyond the operand: a valid row (their products only reach rows the buffer stores drop)
+          dma16(gP + (size_t)row * a.ldp + chunk * 8, dst + inst * 1024);
+          ++n;
+        }
+      }
+    }
+    ++t_issue;
+    q_issue = q_issue == C::R - 1 ? 0 : q_issue + 1;
+    return sgpr(n);
+  };
+
+  // ------------------------------------------------------------------ weight slice -> registers (once)
+  Frag<bf16> bq[C::KS][C::NT];
+  // bias slice of the workgroup -> LDS (accumulators start from it)
+  if (tid < C::BJ) {
+    const int j = cs * C::BJ + tid;
+    reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = (a.e.bias != nullptr && j < a.J) ? a.e.bias[j] : 0.0f;
+  }
+  int ops = 0;            // vector-memory instructions this wave has issued since the ring started (exact: every access below is unconditional)
+  int mk[C::R - 1];       // mk[k] = value of `ops` right after this wave's DMA share of tile (current + 1 + k)
+  int mark_first = 0;
+  if constexpr (C::QKS) {
+    // K-strided weight W[k][j]: slabs of 32 k rows through LDS (the ring's memory, before the ring starts), fragments by transposed reads
+    typename C::ImgQ st;
+#pragma unroll
+    for (int s0 = 0; s0 < C::KS; s0 += C::Q_ROUND) {
+#pragma unroll
+      for (int k = 0; k < C::Q_ROUND; ++k)
+        if (s0 + k < C::KS) {
+          st.init(gQ, a.ldq, cs * C::BJ, (s0 + k) * 32, a.J, wave, lane);
+          st.stage(smem + k * C::ImgQ::BYTES, (s0 + k) * 32, C::K, a.ldq, wave);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < C::Q_ROUND; ++k)
+        if (s0 + k < C::KS) {
+#pragma unroll
+          for (int ct = 0; ct < C::NT; ++ct) bq[s0 + k][ct] = C::ImgQ::frag(smem + k * C::ImgQ::BYTES, wave * C::WJ + ct * 16, 0, lane);
+        }
+      __syncthreads();
+    }
+  }
+  // ring prologue: R - 1 tiles in flight (behind the bias store / the weight prologue, whose barriers are done)
+  {
+    issue();
+    mark_first = 0;  // (ops counted from here: the first tile's share is the oldest entry)
+#pragma unroll
+    for (int k = 0; k < C::R - 2; ++k) {
+      ops += issue();
+      mk[k] = ops;
+    }
+    mk[C::R - 2] = ops;
+  }
+  if constexpr (!C::QKS) {
+    // K-contiguous weight W[j][k]: a fragment is 16 bytes per lane at W[j0 + c][32 s + 8 g ...] - loaded in place, behind the ring's first requests
+    const bf16* qrow = gQ + (size_t)(active ? jw0 + c : 0) * a.ldq + 8 * g;
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s)
+#pragma unroll
+      for (int ct = 0; ct < C::NT; ++ct) bq[s][ct].v = *reinterpret_cast<const bf16x8*>(qrow + (size_t)ct * 16 * a.ldq + s * 32);
+  }
+
+  // ------------------------------------------------------------------ matrix slot
+  f32x4 acc[C::NT];
+  const int fb0 = ((c >> 3) * 64 + g * 8 + (c & 7)) * 16;       // lane's byte offset of slab 0 inside a tile image (regular octets)
+  const int fb1 = ((C::KS / 2) * 128 + g * 16 + c) * 16;        // ... of the last slab when KS is odd (16 rows x 4 chunks)
+  auto matrix = [&](int slot) {
+    const char* img = smem + slot * C::TILE_BYTES;
+    const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF) + wave * C::WJ + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < C::NT; ++ct) acc[ct] = *reinterpret_cast<const f32x4*>(bl + ct * 16);
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+      Frag<bf16> p;
+      if ((C::KS & 1) && s == C::KS - 1) p.v = *reinterpret_cast<const bf16x8*>(img + fb1);
+      else p.v = *reinterpret_cast<const bf16x8*>(img + fb0 + (s >> 1) * 2048 + (s & 1) * 512);
+#pragma unroll
+      for (int ct = 0; ct < C::NT; ++ct) acc[ct] = mma(bq[s][ct], p, acc[ct]);
+    }
+  };
+
+  // ------------------------------------------------------------------ epilogue: registers -> memory (buffer accesses, rows beyond I dropped by the bounds check)
+  // Pair (column tiles 0, 1): v_permlane16_swap gives every lane 8 consecutive columns - even g: tile 0, odd g: tile 1 -, one 16-byte access per lane.
+  // Tile 2 (NT = 3): the same swap against itself, the lanes with even g hold its 8-column halves, the others point outside the buffer.
+  constexpr unsigned OOB = 0x7FFFFFF0u;
+  u32x4 aux01, aux2;  // EPI_DGELU: the saved gelu' of the tile, requested in front of the DMA share (its wait must not include that share)
+  auto epi_pre = [&](int t) -> int {
+    if constexpr (C::EPI == EPI_DGELU) {
+      if (!active) return 0;
+      const int row = t * 16 + c;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.e.aux), 0, (int)min((long)a.I * a.e.ld_aux * 2, 0x7FFFFFF0L), 0x00020000);
+      aux01 = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(row * a.e.ld_aux + jw0 + (g & 1) * 16 + (g >> 1) * 8) * 2u, 0, V4H_SAVED_AUX);
+      if constexpr (C::NT == 3)
+        aux2 = __builtin_amdgcn_raw_buffer_load_b128(rx, (g & 1) ? OOB : (unsigned)(row * a.e.ld_aux + jw0 + 32 + (g >> 1) * 8) * 2u, 0, V4H_SAVED_AUX);
+      return C::EPI_ST;
+    }
+    return 0;
+  };
+  auto epi_post = [&](int t) -> int {
+    if (!active) return 0;
+    const int row = t * 16 + c;
+    const int col01 = jw0 + (g & 1) * 16 + (g >> 1) * 8, col2 = jw0 + 32 + (g >> 1) * 8;
+    if constexpr (C::EPI == EPI_STORE) {
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(acc[0], acc[1]), ro, (unsigned)(row * a.e.ldo + col01) * 2u, 0, 0);
+      if constexpr (C::NT == 3)
+        __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(acc[2], acc[2]), ro, (g & 1) ? OOB : (unsigned)(row * a.e.ldo + col2) * 2u, 0, 0);
+      return C::EPI_ST;
+    } else if constexpr (C::EPI == EPI_GELU) {  // out = gelu'(pre) (training only), out2 = gelu(pre)
+      const bool train = a.e.out != nullptr;
+      const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(a.e.out2, 0, (int)min((long)a.I * a.e.ldo2 * 2, 0x7FFFFFF0L), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, train ? (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L) : 0, 0x00020000);
+      f32x4 y[C::NT], d[C::NT];
+#pragma unroll
+      for (int ct = 0; ct < C::NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (train) {
+            float yy, dd;
+            gelu_and_grad<bf16>(acc[ct][r], yy, dd);
+            y[ct][r] = yy;
+            d[ct][r] = dd;
+          } else {
+            y[ct][r] = gelu_only<bf16>(acc[ct][r]);
+            d[ct][r] = 0.f;
+          }
+        }
+      __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(d[0], d[1]), rd, (unsigned)(row * a.e.ldo + col01) * 2u, 0, V4H_SAVED_AUX);  // (inference: zero-sized buffer, dropped)
+      __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(y[0], y[1]), ro2, (unsigned)(row * a.e.ldo2 + col01) * 2u, 0, 0);
+      if constexpr (C::NT == 3) {
+        __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(d[2], d[2]), rd, (g & 1) ? OOB : (unsigned)(row * a.e.ldo + col2) * 2u, 0, V4H_SAVED_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(swap_pair_bf16(y[2], y[2]), ro2, (g & 1) ? OOB : (unsigned)(row * a.e.ldo2 + col2) * 2u, 0, 0);
+      }
+      return C::EPI_OPS;
+    } else {  // EPI_DGELU: out = acc * aux
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
+      {
+        f32x8 v = swap_pair(acc[0], acc[1]);
+        const bf16x8 x = __builtin_bit_cast(bf16x8, aux01);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v.v[r] *= (float)x[r];
+        __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro, (unsigned)(row * a.e.ldo + col01) * 2u, 0, 0);
+      }
+      if constexpr (C::NT == 3) {
+        f32x8 v = swap_pair(acc[2], acc[2]);
+        const bf16x8 x = __builtin_bit_cast(bf16x8, aux2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v.v[r] *= (float)x[r];
+        __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro, (g & 1) ? OOB : (unsigned)(row * a.e.ldo + col2) * 2u, 0, 0);
+      }
+      return C::EPI_ST;
+    }
+  };
+
+  // ------------------------------------------------------------------ the walk over this workgroup's tiles
+  auto slot_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // tile t_begin has landed for every wave (this wave: everything older than its newer shares), bias and weight fragments are in place
+  wait_vmcnt64(sgpr(ops - mark_first));
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the bias slice is written (the raw barrier below does not wait for LDS stores)
+  slot_barrier();
+  int slot = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    // Interval t (between two barriers): every wave computes tile t from ring slot `slot`, requests its share of tile t + R - 1 into the slot tile t - 1
+    // left at the last barrier, and writes one finished tile: half 0 the one it has just computed (matrix slot first), half 1 the previous one (auxiliary
+    // slot first, its accumulators survive the barrier) - the two waves of a SIMD run the two slots in opposite order.
+    if (half == 0) {
+      if (active) matrix(slot);
+      ops += epi_pre(t);
+      ops += issue();
+      mk[C::R - 2] = ops;
+      ops += epi_post(t);
+    } else {
+      if (t > t_begin) ops += epi_pre(t - 1);
+      ops += issue();
+      mk[C::R - 2] = ops;
+      if (t > t_begin) ops += epi_post(t - 1);
+      if (active) matrix(slot);
+    }
+    // before the barrier: this wave's share of tile t + 1 has landed (everything it issued afterwards may stay in flight)
+    wait_vmcnt64(sgpr(ops - mk[0]));
+#pragma unroll
+    for (int k = 0; k < C::R - 2; ++k) mk[k] = mk[k + 1];
+    slot_barrier();
+    slot = slot == C::R - 1 ? 0 : slot + 1;
+  }
+  if (half == 1 && t_end > t_begin) {
+    epi_pre(t_end - 1);
+    epi_post(t_end - 1);
+  }
+}
+
+// Column tiles per wave for a J-wide output: the shape that wastes the fewest wave slices of the last column slice (3 tiles = 48 columns per wave where
+// that is at least as full - fewer LDS fragment reads per MFMA).
+inline int v4h_gemm3_pick_nt(int J) {
+  auto waste = [&](int wj) {
+    const int ws = (J + wj - 1) / wj, slices = (ws + 7) / 8;  // wave slices, column slices of 8 waves
+    return (double)(slices * 8 - ws) / (slices * 8);
+  };
+  if (J % 48 != 0) return J % 32 == 0 ? 2 : 0;
+  if (J % 32 != 0) return 3;
+  return waste(48) <= waste(32) + 1e-9 ? 3 : 2;
+}
+inline bool v4h_gemm3_eligible(const GemmArgs& a, int K) {
+  return a.K == K && a.I >= 2048 && v4h_gemm3_pick_nt(a.J) != 0 && a.ldp % 8 == 0 && a.ldq % 8 == 0 && a.e.ldo % 8 == 0 && ((uintptr_t)a.P % 16) == 0 &&
+         ((uintptr_t)a.Q % 16) == 0 && ((uintptr_t)a.e.out % 16) == 0 && (long)a.I * a.e.ldo * 2 < 0x7FFFFFF0L && (long)a.I * a.ldp * 2 < (1L << 40);
+}
+
+template <class C> int v4h_gemm3_launch(const GemmArgs& a, hipStream_t stream, const char* name) {
+  V4H_CHECK_ARG(a.I > 0 && a.J > 0 && a.K == C::K, "%s: K=%d is not the %d this kernel keeps in registers (I=%d J=%d)", name, a.K, C::K, a.I, a.J);
+  V4H_CHECK_ARG(a.J % C::WJ == 0, "%s: J=%d must be a multiple of %d", name, a.J, C::WJ);
+  V4H_CHECK_ARG(a.ldp % 8 == 0 && a.ldq % 8 == 0 && ((uintptr_t)a.P % 16) == 0 && ((uintptr_t)a.Q % 16) == 0, "%s: operands must be 16-byte aligned with row strides of whole chunks", name);
+  V4H_CHECK_ARG(((uintptr_t)a.e.out % 16) == 0 && a.e.ldo % 8 == 0 && (long)a.I * a.e.ldo * 2 < 0x7FFFFFF0L, "%s: output must be 16-byte aligned, row stride of whole chunks, below 2 GB", name);
+  if (C::EPI == EPI_GELU) V4H_CHECK_ARG(a.e.out2 != nullptr && ((uintptr_t)a.e.out2 % 16) == 0 && a.e.ldo2 % 8 == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L, "%s: second output", name);
+  if (C::EPI == EPI_DGELU) V4H_CHECK_ARG(a.e.aux != nullptr && ((uintptr_t)a.e.aux % 16) == 0 && a.e.ld_aux % 8 == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L, "%s: auxiliary operand", name);
+  const int ncs = (a.J + C::BJ - 1) / C::BJ, nrt = (a.I + 15) / 16;
+  int nrg = v4h_compute_units() / ncs;
+  if (nrg > nrt) nrg = nrt;
+  V4H_CHECK_ARG(nrg >= 1, "%s: %d column slices do not fit the %d compute units", name, ncs, v4h_compute_units());
+  const int wpx = (ncs * nrg + 7) / 8;
+  static DeviceOnce lds_attr;
+  if (int rc = lds_attr.ensure([&]() -> hipError_t {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+      }, name, "reserve the ring's LDS")) return rc;
+  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx);
+  V4H_CHECK_LAUNCH(name);
+  return V4H_OK;
+}
