@@ -77,11 +77,13 @@ inline bool on_ring(const GemmArgs& a, int klen, int bit) {
 
 // The K = hidden_dim contractions (qkv, attn.proj, fc1 + GELU forward; attn.proj and fc2 x GELU' input gradients) on the weight-stationary kernel:
 // the weight slice of a workgroup lives in registers, only activation rows stream (v4h_gemm3.h).  V4H_GEMM3=0: off (A/B hook).
-int g_ws = env_flag("V4H_GEMM3", 1);
+// Contraction classes on it under KERNEL_AUTO (bits: 1 forward plain store with >= 960 output columns - qkv -, 2 forward plain store below that - attn.proj -,
+// 4 forward GELU, 8 dgrad plain store, 16 dgrad DGELU).  V4H_GEMM3 overrides (A/B hook); KERNEL_WS takes every eligible class.
+int g_ws = env_flag("V4H_GEMM3", 3) & 31;
 constexpr int WS_K = 480;
-inline bool on_ws(const GemmArgs& a) {
+inline bool on_ws(const GemmArgs& a, int bit) {
   if (g_kernel == KERNEL_TWO_WG || g_kernel == KERNEL_RING) return false;
-  return (g_ws != 0 || g_kernel == KERNEL_WS) && v4h_gemm3_eligible(a, WS_K);
+  return ((g_ws & bit) != 0 || g_kernel == KERNEL_WS) && v4h_gemm3_eligible(a, WS_K);
 }
 template <bool QKS, int EPI> int run_ws(const GemmArgs& a, hipStream_t s, const char* name) {
   if (v4h_gemm3_pick_nt(a.J) == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
@@ -113,8 +115,8 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if (epi == EPI_SILU) return v4h_small::smallm_launch<false, EPI_SILU>(a, s, "gemm_small/silu");
       if (epi == EPI_COND_SUM) return v4h_small::smallm_launch<false, EPI_COND_SUM>(a, s, "gemm_small/cond_sum");
     }
-    if (epi == EPI_STORE && on_ws(a)) return run_ws<false, EPI_STORE>(a, s, "gemm3_fwd/store");
-    if (epi == EPI_GELU && on_ws(a) && a.e.out2 != nullptr && a.e.ldo2 % 8 == 0 && ((uintptr_t)a.e.out2 % 16) == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L)
+    if (epi == EPI_STORE && on_ws(a, a.J >= 960 ? 1 : 2)) return run_ws<false, EPI_STORE>(a, s, "gemm3_fwd/store");
+    if (epi == EPI_GELU && on_ws(a, 4) && a.e.out2 != nullptr && a.e.ldo2 % 8 == 0 && ((uintptr_t)a.e.out2 % 16) == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L)
       return run_ws<false, EPI_GELU>(a, s, "gemm3_fwd/gelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
     if (epi == EPI_GELU && on_ring(a, a.K, a.e.out != nullptr ? 2 : 32) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
@@ -154,8 +156,8 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
 #endif
   if constexpr (sizeof(T) == 2) {
     if (g_small && epi == EPI_DSILU && v4h_small::smallm_eligible(a)) return v4h_small::smallm_launch<true, EPI_DSILU>(a, s, "gemm_small/dsilu");
-    if (epi == EPI_STORE && on_ws(a)) return run_ws<true, EPI_STORE>(a, s, "gemm3_dgrad/store");
-    if (epi == EPI_DGELU && on_ws(a) && a.e.aux != nullptr && a.e.ld_aux % 8 == 0 && ((uintptr_t)a.e.aux % 16) == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L)
+    if (epi == EPI_STORE && on_ws(a, 8)) return run_ws<true, EPI_STORE>(a, s, "gemm3_dgrad/store");
+    if (epi == EPI_DGELU && on_ws(a, 16) && a.e.aux != nullptr && a.e.ld_aux % 8 == 0 && ((uintptr_t)a.e.aux % 16) == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L)
       return run_ws<true, EPI_DGELU>(a, s, "gemm3_dgrad/dgelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 4)) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
     if (epi == EPI_DGELU && on_ring(a, a.K, 8) && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");
@@ -260,6 +262,11 @@ int select_contraction_kernel(int which) {
 }
 int selected_contraction_kernel() { return g_kernel; }
 
+#ifdef V4H_GEMM3_STAMPS
+extern "C" int v4h_debug_gemm3_stamps(void* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(v4h_gemm3_stamp_buf), sizeof(v4h_gemm3_stamp_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef V4H_ABLATIONS
 #ifdef V4H_GEMM2_STAMPS
 extern "C" int v4h_debug_gemm2_stamps(void* host_out) {

@@ -17,8 +17,8 @@
 //   * the grid is cut into EQUAL shares: workgroup = (column slice, contiguous range of 16-row tiles), ranges differing by at most one tile - no tile rounds;
 //   * ping-pong without extra registers: the two waves of a SIMD run matrix slot (45 MFMAs + 15 fragment reads) and auxiliary slot (epilogue of the tile
 //     just finished, DMA of the tile five ahead) in opposite order between two barriers, so a SIMD's matrix pipe nearly always has a wave with MFMAs to issue;
-//   * A image [octet of chunks][row half][chunk][row] (tools/lds_model.py conventions): DMA pieces are 8 rows x 128 contiguous bytes, and the 16 lanes of
-//     every ds_read_b128 service group fall on 16 different 16-byte bank groups (derivation in DESIGN.md section 5).
+//   * A image [octet of chunks][16 rows][8 chunks, XOR-swizzled as in v4h_gemm.h]: a DMA piece is 8 rows x 128 contiguous bytes with the lanes of a quad on
+//     consecutive chunks of one row, and the 16 lanes of every ds_read_b128 service group fall on 16 different 16-byte bank groups (tools/lds_model.py).
 #pragma once
 #include "v4h_gemm2.h"
 
@@ -42,12 +42,66 @@ template <bool QKS_, int EPI_, int NT_, int KS_ = 15> struct Gemm3Cfg {
   static_assert(NI == KS && LDS_BYTES <= 160 * 1024 && Q_ROUND >= 1, "ring shape");
 };
 
-template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kernel(const GemmArgs a, int ncs, int nrg, int wpx) {
+// One fragment read of the tile image (slab S) and the chain of matrix steps, as templates: every LDS offset, wait count and register index is a constant.
+template <int KS, int S> V4H_DEV void g3_read(Frag<bf16>& f, unsigned a0, unsigned a0h, unsigned a1) {
+  if constexpr ((KS & 1) && S == KS - 1) asm volatile("ds_read_b128 %0, %1" : "=v"(f.v) : "v"(a1));
+  else if constexpr (S & 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(a0h), "n"((S >> 1) * 2048));
+  else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(a0), "n"((S >> 1) * 2048));
+}
+template <int KS, int NT, int S> struct G3Step {
+  static V4H_DEV void run(f32x4 (&acc)[NT], const Frag<bf16> (&bq)[KS][NT], Frag<bf16> (&p)[3], unsigned a0, unsigned a0h, unsigned a1) {
+#if defined(V4H_G3_EXP) && V4H_G3_EXP == 1   // timing experiment (wrong results): no fragment reads behind the first two
+    constexpr int younger = S == 0 ? 1 : 0;
+#elif defined(V4H_G3_EXP) && V4H_G3_EXP == 2  // timing experiment: one slab ahead only
+    if constexpr (S + 2 < KS && S % 1 == 0) g3_read<KS, S + 2>(p[(S + 2) % 3], a0, a0h, a1);
+    constexpr int younger = 0 * S;
+#else
+    if constexpr (S + 2 < KS) g3_read<KS, S + 2>(p[(S + 2) % 3], a0, a0h, a1);
+    constexpr int younger = (KS - 1 - S) < 2 ? (KS - 1 - S) : 2;  // reads issued behind the one this step needs
+#endif
+    if constexpr (S == 0) {  // the bias reads (into the accumulators) are older still: the same wait covers them
+      if constexpr (NT == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0].v), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "n"(younger));
+      else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(p[0].v), "+v"(acc[0]), "+v"(acc[1]) : "n"(younger));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(p[S % 3].v) : "n"(younger));
+    }
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = mma(bq[S][ct], p[S % 3], acc[ct]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S + 1 < KS) G3Step<KS, NT, S + 1>::run(acc, bq, p, a0, a0h, a1);
+  }
+};
+
+#ifdef V4H_GEMM3_STAMPS
+// Diagnostic build only (V4H_EXTRA_FLAGS="-DV4H_ABLATIONS -DV4H_GEMM3_STAMPS"): every wave stamps the shader clock at the boundaries of its slots - into 4 KB of
+// LDS behind the ring (no vector-memory instruction, the counted waits are untouched) - and copies them out at the end (tools/experiments/gemm3_stamps.py).
+constexpr int G3_ST_N = 128;
+__device__ unsigned v4h_gemm3_stamp_buf[256 * 8 * G3_ST_N];
+#define V4H_G3_STAMP()                                                                                                  \
+  do {                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    unsigned long long now_;                                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                                        \
+    if (lane == 0 && st_n < G3_ST_N) reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[wave * G3_ST_N + st_n] = (unsigned)now_; \
+    ++st_n;                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  } while (0)
+#else
+#define V4H_G3_STAMP() do { } while (0)
+#endif
+
+// ncs column slices x nrg row groups; wpx = shares per XCD; rcp_ncs = ceil(2^32 / ncs) (share / ncs without a division sequence); row group rg walks
+// tiles [rg * tq + min(rg, tr), ...) with tq = tiles / nrg, tr = tiles % nrg: ranges that differ by at most one tile.
+template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kernel(const GemmArgs a, int ncs, int nrg, int wpx, unsigned rcp_ncs, int tq, int tr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < C::NW);
   const int half = wave >> 2;
+#ifdef V4H_GEMM3_STAMPS
+  int st_n = 0;
+#endif
+  V4H_G3_STAMP();  // 0: start
   auto sgpr = [](int x) { return __builtin_amdgcn_readfirstlane(x); };
   const bf16* gP = reinterpret_cast<const bf16*>(a.P);
   const bf16* gQ = reinterpret_cast<const bf16*>(a.Q);
@@ -56,9 +110,8 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   // list, so the workgroups of one XCD are consecutive row groups with ALL their column slices - an activation tile is fetched into that L2 once (speed only).
   const int share = (int)(blockIdx.x & 7) * wpx + (int)(blockIdx.x >> 3);
   if (share >= ncs * nrg) return;
-  const int rg = sgpr(share / ncs), cs = share - rg * ncs;
-  const int nrt = (a.I + 15) >> 4;
-  const int t_begin = (int)((long)rg * nrt / nrg), t_end = (int)((long)(rg + 1) * nrt / nrg);
+  const int rg = sgpr((int)__umulhi((unsigned)share, rcp_ncs)), cs = share - rg * ncs;
+  const int t_begin = rg * tq + min(rg, tr), t_end = t_begin + tq + (rg < tr ? 1 : 0);
   const int jw0 = cs * C::BJ + wave * C::WJ;  // this wave's first column
   const bool active = jw0 < a.J;              // (wave-uniform; J is a whole number of wave slices)
   const int c = lane & 15, g = lane >> 4;
@@ -75,12 +128,16 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
         const int inst = wave + k * C::NW;  // (scalar)
         if (inst < C::NI) {
           int row, chunk;
+          // (consecutive lanes read consecutive 16-byte chunks of ONE row: the address unit coalesces a quad of lanes into one 64-byte access.  The first
+          //  form of the image had the rows running fastest - every lane of a quad in another row, i.e. four lookups per quad.)
           if (inst < C::NREG) {
-            row = row0 + (inst & 1) * 8 + (lane & 7);
-            chunk = (inst >> 1) * 8 + (lane >> 3);
+            const int r = (inst & 1) * 8 + (lane >> 3);  // row of the tile; the image keeps its 8 chunks of an octet at position kc ^ (r & 6)
+            row = row0 + r;
+            chunk = (inst >> 1) * 8 + ((lane & 7) ^ (r & 6));
           } else {
-            row = row0 + (lane & 15);
-            chunk = (C::KS / 2) * 8 + (lane >> 4);
+            const int r = lane >> 2;                     // last half octet (KS odd): 16 rows x 4 chunks at position kc ^ ((r & 4) >> 1)
+            row = row0 + r;
+            chunk = (C::KS / 2) * 8 + ((lane & 3) ^ ((r & 4) >> 1));
           }
           row = min(row, a.I - 1);  // rows beyond the operand: a valid row (their products only reach rows the buffer stores drop)
           dma16(gP + (size_t)row * a.ldp + chunk * 8, dst + inst * 1024);
@@ -95,10 +152,12 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
 
   // ------------------------------------------------------------------ weight slice -> registers (once)
   Frag<bf16> bq[C::KS][C::NT];
-  // bias slice of the workgroup -> LDS (accumulators start from it)
-  if (tid < C::BJ) {
+  // bias slice of the workgroup -> LDS (accumulators start from it): requested first, stored behind everything else the prologue requests, so that
+  // nothing waits for its round trip
+  float bias_v = 0.0f;
+  {
     const int j = cs * C::BJ + tid;
-    reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = (a.e.bias != nullptr && j < a.J) ? a.e.bias[j] : 0.0f;
+    if (tid < C::BJ && a.e.bias != nullptr && j < a.J) bias_v = a.e.bias[j];
   }
   int ops = 0;            // vector-memory instructions this wave has issued since the ring started (exact: every access below is unconditional)
   int mk[C::R - 1];       // mk[k] = value of `ops` right after this wave's DMA share of tile (current + 1 + k)
@@ -124,6 +183,7 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       __syncthreads();
     }
   }
+  V4H_G3_STAMP();  // 1: (dgrad form: weight fragments in registers)
   // ring prologue: R - 1 tiles in flight (behind the bias store / the weight prologue, whose barriers are done)
   {
     issue();
@@ -138,29 +198,51 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   if constexpr (!C::QKS) {
     // K-contiguous weight W[j][k]: a fragment is 16 bytes per lane at W[j0 + c][32 s + 8 g ...] - loaded in place, behind the ring's first requests
     const bf16* qrow = gQ + (size_t)(active ? jw0 + c : 0) * a.ldq + 8 * g;
+    // (column tile by column tile, slabs in order: consecutive requests of a wave touch the two 64-byte halves of the same 128-byte lines.  Odd row groups
+    //  walk the slabs downwards: two request fronts over the weight instead of one)
+    if (rg & 1) {
 #pragma unroll
-    for (int s = 0; s < C::KS; ++s)
+      for (int ct = 0; ct < C::NT; ++ct)
 #pragma unroll
-      for (int ct = 0; ct < C::NT; ++ct) bq[s][ct].v = *reinterpret_cast<const bf16x8*>(qrow + (size_t)ct * 16 * a.ldq + s * 32);
+        for (int s = C::KS - 1; s >= 0; --s) bq[s][ct].v = *reinterpret_cast<const bf16x8*>(qrow + (size_t)ct * 16 * a.ldq + s * 32);
+    } else {
+#pragma unroll
+      for (int ct = 0; ct < C::NT; ++ct)
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) bq[s][ct].v = *reinterpret_cast<const bf16x8*>(qrow + (size_t)ct * 16 * a.ldq + s * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 
+  if (tid < C::BJ) reinterpret_cast<float*>(smem + C::BIAS_OFF)[tid] = bias_v;
+  V4H_G3_STAMP();  // 2: ring requested, weight loads issued
+#ifdef V4H_GEMM3_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  V4H_G3_STAMP();  // 3: (stamped build only) everything requested so far has arrived
   // ------------------------------------------------------------------ matrix slot
   f32x4 acc[C::NT];
-  const int fb0 = ((c >> 3) * 64 + g * 8 + (c & 7)) * 16;       // lane's byte offset of slab 0 inside a tile image (regular octets)
-  const int fb1 = ((C::KS / 2) * 128 + g * 16 + c) * 16;        // ... of the last slab when KS is odd (16 rows x 4 chunks)
+  // tile image: per octet of chunks (two K = 32 slabs) a 16-row x 8-chunk block in the layout of v4h_gemm.h's K-contiguous images (chunk kc of row r at
+  // position kc ^ (r & 6): conflict-free ds_read_b128 by tools/lds_model.py), the last half octet (KS odd) as 16 rows x 4 chunks at kc ^ ((r & 4) >> 1)
+  const int fb0 = (c * 8 + (g ^ (c & 6))) * 16;                          // lane's byte offset of the even slab of octet 0
+  const int fb0h = (c * 8 + ((4 + g) ^ (c & 6))) * 16;                   // ... of the odd slab
+  const int fb1 = ((C::KS / 2) * 128 + c * 4 + (g ^ ((c & 4) >> 1))) * 16;  // ... of the last slab when KS is odd
+  // 45 (30) MFMAs on fragments requested two slabs ahead, three fragment buffers rotating.  The LDS reads and their waits are written in assembly: with
+  // plain loads the compiler's waitcnt pass drains lgkmcnt(0) every third slab - right behind a read it has just issued - and the slot takes 1460 clocks for
+  // 720 clocks of matrix pipe (its own first order - two reads, a full wait, six MFMAs - 1610; profiles/r05_notes.md).  Here every wait is counted: before
+  // the MFMAs of slab s only the reads up to slab s have to be back (LDS returns in order), the two younger ones stay in flight.  The accumulators are the
+  // destination of the bias reads, which are the oldest of the slot.
+  const unsigned lds0 = (unsigned)(uintptr_t)((V4H_LDS char*)smem);
+  const unsigned bias_addr = lds0 + C::BIAS_OFF + (wave * C::WJ + 4 * g) * 4;
   auto matrix = [&](int slot) {
-    const char* img = smem + slot * C::TILE_BYTES;
-    const float* bl = reinterpret_cast<const float*>(smem + C::BIAS_OFF) + wave * C::WJ + 4 * g;
+    const unsigned a0 = lds0 + slot * C::TILE_BYTES + fb0, a0h = lds0 + slot * C::TILE_BYTES + fb0h, a1 = lds0 + slot * C::TILE_BYTES + fb1;
+    Frag<bf16> p[3];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ct = 0; ct < C::NT; ++ct) acc[ct] = *reinterpret_cast<const f32x4*>(bl + ct * 16);
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) {
-      Frag<bf16> p;
-      if ((C::KS & 1) && s == C::KS - 1) p.v = *reinterpret_cast<const bf16x8*>(img + fb1);
-      else p.v = *reinterpret_cast<const bf16x8*>(img + fb0 + (s >> 1) * 2048 + (s & 1) * 512);
-#pragma unroll
-      for (int ct = 0; ct < C::NT; ++ct) acc[ct] = mma(bq[s][ct], p, acc[ct]);
-    }
+    for (int ct = 0; ct < C::NT; ++ct) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(acc[ct]) : "v"(bias_addr), "n"(ct * 64));
+    g3_read<C::KS, 0>(p[0], a0, a0h, a1);
+    g3_read<C::KS, 1>(p[1], a0, a0h, a1);
+    G3Step<C::KS, C::NT, 0>::run(acc, bq, p, a0, a0h, a1);
   };
 
   // ------------------------------------------------------------------ epilogue: registers -> memory (buffer accesses, rows beyond I dropped by the bounds check)
@@ -242,17 +324,34 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // Counted wait.  In the steady state the count is one of two constants - (R - 1) epilogues + (R - 2) DMA shares of 1 or 2 instructions - and takes an
+  // immediate; anything else (head and tail of the walk, waves without columns) goes through the computed jump (176 clocks per call, measured).
+  auto wait_counted = [&](int n) {
+    constexpr int S2 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * 2, S1 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * 1;
+    static_assert(S2 <= 63, "vmcnt immediate");
+    if (n == S2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S2) : "memory");
+    else if (n == S1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S1) : "memory");
+    else wait_vmcnt64(n);
+  };
   // tile t_begin has landed for every wave (this wave: everything older than its newer shares), bias and weight fragments are in place
   wait_vmcnt64(sgpr(ops - mark_first));
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the bias slice is written (the raw barrier below does not wait for LDS stores)
   slot_barrier();
+  V4H_G3_STAMP();  // 4: first barrier passed
   int slot = 0;
   for (int t = t_begin; t < t_end; ++t) {
     // Interval t (between two barriers): every wave computes tile t from ring slot `slot`, requests its share of tile t + R - 1 into the slot tile t - 1
     // left at the last barrier, and writes one finished tile: half 0 the one it has just computed (matrix slot first), half 1 the previous one (auxiliary
     // slot first, its accumulators survive the barrier) - the two waves of a SIMD run the two slots in opposite order.
+#if defined(V4H_G3_EXP) && V4H_G3_EXP == 3   // timing experiment (wrong results): matrix slots only
+    if (active) matrix(slot);
+    V4H_G3_STAMP();
+    mk[C::R - 2] = ops;
+    if (t_end == 12345678) { ops += epi_pre(t); ops += issue(); ops += epi_post(t); }
+#else
     if (half == 0) {
       if (active) matrix(slot);
+      V4H_G3_STAMP();  // 5 + 4 i: first slot done
       ops += epi_pre(t);
       ops += issue();
       mk[C::R - 2] = ops;
@@ -262,19 +361,29 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       ops += issue();
       mk[C::R - 2] = ops;
       if (t > t_begin) ops += epi_post(t - 1);
+      V4H_G3_STAMP();
       if (active) matrix(slot);
     }
+#endif
+    V4H_G3_STAMP();  // 6 + 4 i: second slot done
     // before the barrier: this wave's share of tile t + 1 has landed (everything it issued afterwards may stay in flight)
-    wait_vmcnt64(sgpr(ops - mk[0]));
+    wait_counted(sgpr(ops - mk[0]));
+    V4H_G3_STAMP();  // 7 + 4 i: counted wait done
 #pragma unroll
     for (int k = 0; k < C::R - 2; ++k) mk[k] = mk[k + 1];
     slot_barrier();
+    V4H_G3_STAMP();  // 8 + 4 i: barrier passed
     slot = slot == C::R - 1 ? 0 : slot + 1;
   }
   if (half == 1 && t_end > t_begin) {
     epi_pre(t_end - 1);
     epi_post(t_end - 1);
   }
+#ifdef V4H_GEMM3_STAMPS
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  for (int k = lane; k < G3_ST_N; k += 64)
+    v4h_gemm3_stamp_buf[((blockIdx.x & 255) * 8 + wave) * G3_ST_N + k] = reinterpret_cast<unsigned*>(smem + C::LDS_BYTES)[wave * G3_ST_N + k];
+#endif
 }
 
 // Column tiles per wave for a J-wide output: the shape that wastes the fewest wave slices of the last column slice (3 tiles = 48 columns per wave where
@@ -305,11 +414,17 @@ template <class C> int v4h_gemm3_launch(const GemmArgs& a, hipStream_t stream, c
   if (nrg > nrt) nrg = nrt;
   V4H_CHECK_ARG(nrg >= 1, "%s: %d column slices do not fit the %d compute units", name, ncs, v4h_compute_units());
   const int wpx = (ncs * nrg + 7) / 8;
+  const unsigned rcp_ncs = (unsigned)((0x100000000ULL + ncs - 1) / ncs);  // exact quotient for share < 2^16
+  const int tq = nrt / nrg, tr = nrt % nrg;
   static DeviceOnce lds_attr;
   if (int rc = lds_attr.ensure([&]() -> hipError_t {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 4096);
       }, name, "reserve the ring's LDS")) return rc;
-  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx);
+#ifdef V4H_GEMM3_STAMPS
+  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES + 4096, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
+#else
+  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
+#endif
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;
 }
