@@ -260,7 +260,7 @@ def launch_ranks(n):
     return 0
 
 
-def sampling_rates(model, w, device, peak, batch=256, reps=2):
+def sampling_rates(model, w, device, peak, batch=256, reps=8):
     """BASELINE config 5 (ds2 shape sampling, one GPU): CaloChallengeCFM.sample_batch (calochallenge_cfm/model.py:68-94) at the reference's
     sampling batch of 256 with its default fixed-grid RK4 (step 0.05 = 80 network evaluations) and with Heun (40), timed after the training region."""
     T, P = tokens_and_patch_dim(w)
@@ -274,14 +274,17 @@ def sampling_rates(model, w, device, peak, batch=256, reps=2):
         model.odeint_kwargs = {"method": method, "options": {"step_size": 0.05}}
         model.sample_batch(c)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        times = []
+        for _ in range(reps):  # every batch timed on its own (host clock around a synchronised batch): the MEDIAN is reported, min / max beside it
+            t0 = time.perf_counter()
             s = model.sample_batch(c)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
         assert bool(torch.isfinite(s).all())
+        dt = sorted(times)[len(times) // 2]
         tf = nfe * batch * flops / dt / 1e12
-        out[method] = {"nfe": nfe, "showers_per_s": round(batch / dt, 1), "s_per_100k": round(1e5 / batch * dt, 2), "tflops": round(tf, 1), "frac": round(tf / peak, 4)}
+        out[method] = {"nfe": nfe, "batches": reps, "showers_per_s": round(batch / dt, 1), "s_per_100k": round(1e5 / batch * dt, 2), "tflops": round(tf, 1),
+                       "frac": round(tf / peak, 4), "batch_ms_min_median_max": [round(min(times) * 1e3, 2), round(dt * 1e3, 2), round(max(times) * 1e3, 2)]}
     model.odeint_kwargs = saved
     model.train(was_training)
     return out
@@ -532,12 +535,19 @@ def main():
     e0.record()
     step_marks = [] if os.environ.get("V4H_BENCH_STEP_EVENTS") == "1" else None  # diagnostic: one event per step (a barrier packet each, ~0.1 %)
     host_marks = []
-    host_only = os.environ.get("V4H_BENCH_HOST_TIMES") == "1"  # diagnostic: host time of every step() call, nothing added to the stream
+    host_only = os.environ.get("V4H_BENCH_HOST_TIMES") == "1"  # diagnostic: print the host time of every step() call
+    # Always: the host time of every step() call (one perf_counter each, nothing on the stream) -> `host_max_step_call_ms` exposes a stalled call (a 35-80 ms
+    # stall of the runtime inside one launch was seen in round 4); and one timing event per step (a marker packet each, < 0.1 % of a step) ->
+    # `device_ms_per_step_p50` beside the mean: a run whose mean is pulled up by one slow step shows it.
+    call_ms, dev_marks = [], []
     for _ in range(args.steps):
+        tc = time.perf_counter()
         loss, gn = trainer.step(x, c)
+        call_ms.append((time.perf_counter() - tc) * 1e3)
+        dev_marks.append(torch.cuda.Event(enable_timing=True))
+        dev_marks[-1].record()
         if step_marks is not None:
-            step_marks.append(torch.cuda.Event(enable_timing=True))
-            step_marks[-1].record()
+            step_marks.append(dev_marks[-1])
         if step_marks is not None or host_only:
             host_marks.append(time.perf_counter())
     trainer.finish()  # (a pipelined update of the last step is ordered into the timed stream: both clocks below include it)
@@ -602,6 +612,13 @@ def main():
                          "kernel": "whole update step (all launches of one step)", "flop_per_launch": flop_step, "launch_ms": round(dev_ms_step, 4)},
             "mfma_util_pct": round(100.0 * achieved / peak, 2),
         }
+        ts = [e0.elapsed_time(m) for m in dev_marks]
+        per_step = sorted(b - a for a, b in zip([0.0] + ts[:-1], ts))
+        rec["device_ms_per_step_mean"] = round(dev_ms_step, 4)
+        rec["device_ms_per_step_p50"] = round(per_step[len(per_step) // 2], 4)
+        rec["device_ms_per_step_max"] = round(per_step[-1], 4)
+        rec["host_max_step_call_ms"] = round(max(call_ms), 3)
+        rec["host_step_call_ms_p50"] = round(sorted(call_ms)[len(call_ms) // 2], 3)
         if not args.lean and world == 1:  # (profiling runs count the steps of the process: no extra ones; with several ranks a step is a collective)
             # host time to ENQUEUE one step on an idle device (the queue empty, nothing to wait for): below ms_per_step = the device sets the pace
             sync()
@@ -625,6 +642,13 @@ def main():
             rec["box"] = box_calibration(device)
         if world == 1 and not args.no_op_rates:
             rec["gemm_ops"] = op_rates(args.mode, B * T, device)
+            # the step's dominant kernel (18.9 % of its kernel time: the split-K weight gradients of qkv / fc1 / fc2 on the ring kernel), timed in THIS run
+            dom = [v for k, v in rec["gemm_ops"].items() if k.startswith("wgrad") and "proj" not in k]
+            if dom:
+                us = sum(v["us"] for v in dom) / len(dom)
+                tfl = sum(v["tflops"] * v["us"] for v in dom) / sum(v["us"] for v in dom)
+                rec["roofline"]["dominant"] = {"kernel": "gemm2<bf16,wgrad,256x160x64,SLAB_F32,colsum,ping-pong> + slab_reduce (dW = dY^T X of attn.qkv, mlp.fc1, mlp.fc2; cold operands)",
+                                               "us_per_call": round(us, 2), "tflops": round(tfl, 1), "frac": round(tfl / peak, 4), "calls_per_step": 3 * depth}
         if world == 1 and not args.no_sampling and args.workload == "ds2":
             rec["sampling"] = sampling_rates(model, w, device, peak)
         if world == 1 and not args.no_other and args.workload == "ds2":

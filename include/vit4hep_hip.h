@@ -248,6 +248,15 @@ int32_t v4h_adamw_step(float* d_p, const float* d_g, float* d_m, float* d_v, int
 int32_t v4h_adamw_step_sched(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr0, float eta_min,
                              int32_t t_max, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_state_in, int32_t* d_state_out,
                              float max_grad_norm, void* stream, int32_t* d_nonfinite, float* d_gnorm_out);
+/* The same with the shadow parameters of an exponential moving average updated in the pass (ABI 11; the reference keeps them in a
+ * torch_ema.ExponentialMovingAverage and calls ema.update() right behind optimizer.step(), experiments/base_experiment.py:127-134,593-594; torch_ema is
+ * un-vendored and unpinned there - its published update is restated): d_ema (f32, n elements, initialised by the caller with the parameters) becomes
+ * d_ema - (1 - d) (d_ema - p_new) with d = min(ema_decay, (1 + k) / (10 + k)), k = the number of updates applied including this one (state[0] + 1:
+ * torch_ema's num_updates warm-up).  A skipped update leaves the shadow untouched, as the reference's early return does. */
+int32_t v4h_adamw_step_sched_ema(float* d_p, const float* d_g, float* d_m, float* d_v, int64_t n, const float* d_gnorm_sq, float max_norm, float lr0,
+                                 float eta_min, int32_t t_max, float beta1, float beta2, float eps, float weight_decay, const int32_t* d_state_in,
+                                 int32_t* d_state_out, float max_grad_norm, void* stream, int32_t* d_nonfinite, float* d_gnorm_out, float* d_ema,
+                                 float ema_decay);
 /* ODE solver vector updates for sample_batch (calochallenge_cfm/model.py:87-92; torchdiffeq fixed-grid solvers) */
 int32_t v4h_axpby(float* d_out, const float* d_a, const float* d_b, float alpha, float beta, int64_t n, void* stream);
 int32_t v4h_rk4_combine(float* d_y, const float* d_k1, const float* d_k2, const float* d_k3, const float* d_k4, float h, int64_t n, void* stream);

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_product_library_contains_no_ablation_kernels_and_refuses_to_select_one():
     """The ablation builds of the contraction kernels (some wrong by construction: no DMA after the first ring fill, one store per tile ...) and the
     tuning hook that selected them exist only under -DV4H_ABLATIONS.  A default build exports none of them, ignores an environment that asks for one and
-    refuses any selection other than the three exact kernels."""
+    refuses any selection other than the exact kernels (0 automatic, 1 two-workgroup, 2 ring, 3 weight-stationary - round 5)."""
     import subprocess
 
     syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
@@ -47,7 +47,7 @@ def test_product_library_contains_no_ablation_kernels_and_refuses_to_select_one(
     # mangled names of the ring kernel's instantiations: Gemm2Cfg<PKS, QKS, EPI, COLSUM, DBG, PP> - DBG must be 0 and PP true in every one
     for m in re.finditer(rb"8Gemm2CfgILb[01]ELb[01]ELi\d+ELb[01]ELi(\d+)ELb([01])EE", blob):
         assert m.group(1) == b"0" and m.group(2) == b"1", m.group(0)
-    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); print(lib.v4h_selected_contraction_kernel(), lib.v4h_select_contraction_kernel(3), "
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); print(lib.v4h_selected_contraction_kernel(), lib.v4h_select_contraction_kernel(4), "
             "lib.v4h_select_contraction_kernel(-1), lib.v4h_selected_contraction_kernel(), lib.v4h_select_contraction_kernel(2), lib.v4h_selected_contraction_kernel())")
     for env_val, first in (("3", 0), ("10", 0), ("0", 1), ("8", 2), ("-1", 0)):
         env = dict(os.environ, V4H_GEMM2=env_val)
@@ -281,3 +281,18 @@ def test_bench_gpus_n_launches_its_own_ranks_or_fails_loudly():
         assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, r.stderr[-2000:]
     else:
         assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '{"metric"' not in r.stdout
+
+
+def test_unbuilt_options_of_the_surface_raise_instead_of_being_ignored():
+    """checkpoint_grads (nn/vit.py:201-202), optimizers / schedulers other than the fused AdamW + CosineAnnealingLR (base_experiment.py:329-431), an EMA decay
+    outside [0, 1] (torch_ema's check): every option this build does not implement says so at construction."""
+    from vit4hep_amd import ViT
+    from vit4hep_amd.trainer import CFMTrainer
+
+    base = {"hidden_dim": 480, "depth": 1, "num_heads": 6, "patch_dim": 48, "num_patches": [[15, 1, 9]]}
+    with pytest.raises(NotImplementedError, match="checkpoint_grads"):
+        ViT({**base, "checkpoint_grads": True})
+    ViT({**base, "checkpoint_grads": False})
+    for kw, pat in (({"optimizer": "Adam"}, "optimizer 'Adam'"), ({"optimizer": "Lion"}, "autograd route"), ({"scheduler": "OneCycleLR"}, "scheduler 'OneCycleLR'")):
+        with pytest.raises(NotImplementedError, match=pat):
+            CFMTrainer(None, **kw)

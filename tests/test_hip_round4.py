@@ -309,7 +309,11 @@ def test_operand_copies_ahead_of_the_forward_change_nothing():
         runs.append(([float(l) for l, _ in out], {k: v.detach().clone() for k, v in model.state_dict().items()}))
     assert np.allclose(runs[0][0], runs[1][0], rtol=2e-3), (runs[0][0], runs[1][0])  # bf16 mode: atomically summed tensors vary in the last bit run to run
     for k, v in runs[1][1].items():
-        assert U.rel_err(runs[0][1][k], v) < 5e-3, k
+        got = runs[0][1][k]
+        if k.endswith("attn.qkv.bias"):  # the key third's gradient is analytically zero: rounding noise that Adam turns into +-lr per step
+            D = cfg.hidden_dim
+            got, v = torch.cat([got[:D], got[2 * D :]]), torch.cat([v[:D], v[2 * D :]])
+        assert U.rel_err(got, v) < 5e-3, k
 
 
 def test_whole_step_hipgraph_replays_the_update():

@@ -7,6 +7,8 @@
     operator tests of the forward and input-gradient forms at every output width of the block (480 = two column tiles per wave, 1440 and 1920 = three; a
     last column slice with idle waves), row counts that leave workgroups with ranges of different length and a ragged last tile; bias; fc1 + GELU (value and
     derivative, training and inference form) and fc2-dgrad x GELU' against f64; the same operands through the ring kernel give the same numbers.
+  * EMA inside the fused update (reference experiments/base_experiment.py:127-134,593-594,630-631,674 with torch_ema's published update), its checkpoint entry and
+    the averaged-parameters context; the pipelined update's returned gradient norm.
 """
 
 import pytest
@@ -184,3 +186,77 @@ def test_weight_stationary_gelu_and_dgelu(I):
         assert U.rel_err(out, ref) < 6e-3 and U.rms_err(out, ref) < 3e-3
 
     _with_kernel(_lib.KERNEL_WS, run)
+
+
+# ---------------------------------------------------------------------------------------------------------------- EMA in the fused update, pipelined norm
+def _small_trainer(**kw):
+    from vit4hep_amd.trainer import CFMTrainer
+
+    cfg = O.ds2(2)
+    model = U.build_models(cfg, "f32", O.golden_fill(cfg))
+    x, c, g = O.synthetic_batch(cfg, 8, 3)
+    return cfg, model, CFMTrainer(model, lr=1e-3, iterations=100, **kw), x.to(U.DEV), c.to(U.DEV), g
+
+
+def test_ema_follows_torch_ema_arithmetic_and_round_trips():
+    """Six updates with ema_decay = 0.99: after every step the shadow equals torch_ema's update applied to the parameters the step produced
+    (shadow -= (1 - min(decay, (1 + n) / (10 + n))) * (shadow - param), n = number of updates so far) to 1e-6; the checkpoint's "ema" entry has torch_ema's
+    state_dict layout and loads into a fresh trainer; inside average_parameters() the model computes with the shadow, afterwards with the parameters again."""
+    cfg, model, tr, x, c, g = _small_trainer(ema_decay=0.99)
+    shadow = [p.detach().clone() for p in model.parameters()]
+    for n in range(1, 7):
+        t, x0 = O.synthetic_noise(cfg, 8, g)
+        tr.step(x, c, t.to(U.DEV), x0.to(U.DEV))
+        omd = 1.0 - min(0.99, (1 + n) / (10 + n))
+        for s_, p in zip(shadow, model.parameters()):
+            tmp = s_ - p.detach()
+            tmp.mul_(omd)
+            s_.sub_(tmp)
+        sd = tr.ema_state_dict()
+        assert sd["num_updates"] == n and sd["decay"] == 0.99 and sd["collected_params"] is None
+        for a, b in zip(sd["shadow_params"], shadow):
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())), n
+    ck = tr.checkpoint()
+    assert set(ck) == {"model", "optimizer", "scheduler", "ema"} and len(ck["ema"]["shadow_params"]) == len(list(model.parameters()))
+    # fresh trainer from the file
+    cfg2, model2, tr2, _, _, _ = _small_trainer(ema_decay=0.5)
+    tr2.load_state_dict(ck)
+    assert tr2.ema_decay == 0.99
+    for a, b in zip(tr2.ema_state_dict()["shadow_params"], ck["ema"]["shadow_params"]):
+        assert torch.equal(a, b)
+    # the averaged-parameters context
+    t, x0 = O.synthetic_noise(cfg, 8, g)
+    with torch.no_grad():
+        v_param = model.forward((1 - t.to(U.DEV)) * x0.to(U.DEV) + t.to(U.DEV) * x, t.to(U.DEV).view(-1, 1), c).clone()
+        p_before = [p.detach().clone() for p in model.parameters()]
+        with tr.average_parameters():
+            for p, s_ in zip(model.parameters(), shadow):
+                assert float((p - s_).abs().max()) <= 1e-6 * max(1.0, float(s_.abs().max()))
+            v_ema = model.forward((1 - t.to(U.DEV)) * x0.to(U.DEV) + t.to(U.DEV) * x, t.to(U.DEV).view(-1, 1), c).clone()
+        for p, q in zip(model.parameters(), p_before):
+            assert torch.equal(p, q)
+        v_again = model.forward((1 - t.to(U.DEV)) * x0.to(U.DEV) + t.to(U.DEV) * x, t.to(U.DEV).view(-1, 1), c)
+    assert torch.equal(v_again, v_param) and not torch.equal(v_ema, v_param)
+
+
+def test_ema_is_untouched_by_a_skipped_update():
+    """max_grad_norm skip (base_experiment.py:586-591 returns before optimizer.step() AND ema.update()): the shadow stays bit for bit."""
+    cfg, model, tr, x, c, g = _small_trainer(ema_decay=0.9, max_grad_norm=1e-9)
+    tr.iteration = tr.MIN_STEP_SKIP + 1  # past the reference's MIN_STEP_SKIP
+    before = tr.flat_ema.clone()
+    t, x0 = O.synthetic_noise(cfg, 8, g)
+    tr.step(x, c, t.to(U.DEV), x0.to(U.DEV))
+    assert tr.sync_counters()["skipped_max_grad_norm"] == 1 and torch.equal(tr.flat_ema, before)
+
+
+def test_pipelined_update_returns_the_norm_of_the_inline_update():
+    """with pipeline_update the norm's root is written on the library's side stream; what step() returns must be readable right away."""
+    cfg, model, tr, x, c, g = _small_trainer()
+    cfg, model_p, tr_p, _, _, _ = _small_trainer(pipeline_update=True)
+    for _ in range(3):
+        t, x0 = O.synthetic_noise(cfg, 8, g)
+        l0, n0 = tr.step(x, c, t.to(U.DEV), x0.to(U.DEV))
+        l1, n1 = tr_p.step(x, c, t.to(U.DEV), x0.to(U.DEV))
+        assert float(n1) == float(n0) and float(l1) == float(l0)  # read immediately, no finish() in between
+    tr_p.finish()
+    assert torch.equal(tr.flat_p, tr_p.flat_p)

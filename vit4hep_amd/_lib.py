@@ -85,6 +85,7 @@ SIGNATURES = {
     "v4h_sq_norm_accum": (_i32, [_vp, _i64, _vp, _vp]),
     "v4h_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "v4h_adamw_step_sched": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp]),
+    "v4h_adamw_step_sched_ema": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _f32]),
     "v4h_cfm_prepare_z": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "v4h_mse_loss_acc": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "v4h_axpby": (_i32, [_vp, _vp, _vp, _f32, _f32, _i64, _vp]),

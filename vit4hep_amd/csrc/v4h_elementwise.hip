@@ -888,10 +888,14 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 // updates skipped for max_grad_norm, -}; every thread reads state_in, thread 0 of workgroup 0 writes state_out (another 16 bytes: no race with readers).
 // The update runs over up to ADAM_MAX_RANGES element ranges of the flat buffers per launch (one range = the whole buffer, or the slices of one stage of
 // the pipelined update, v4h_vit_update_ahead); `leader` marks the ONE launch of a step that writes state_out and counts a skipped update.
+// EMA (round 5): the shadow parameters of the reference's torch_ema.ExponentialMovingAverage (base_experiment.py:127-134,593-594: ema.update() right behind
+// optimizer.step(), not for a skipped update) in the same pass - one more f32 stream read and written: shadow -= (1 - d) (shadow - p_new) with
+// d = min(decay, (1 + n) / (10 + n)), n = the number of updates applied including this one (torch_ema's num_updates warm-up).
+template <bool EMA>
 __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, const AdamRanges rg,
                                    const float* __restrict__ gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2, float log_b1,
                                    float log_b2, float eps, float wd, const int* __restrict__ state_in, int* __restrict__ state_out, float max_grad_norm,
-                                   int* nonfinite, float* __restrict__ gnorm_out, int leader) {
+                                   int* nonfinite, float* __restrict__ gnorm_out, int leader, float* __restrict__ ema, float ema_decay) {
   const int applied = state_in[0], sched = state_in[1], skipped = state_in[2];
   const bool lead = leader && blockIdx.x == 0 && threadIdx.x == 0;
   float coef = 1.0f;
@@ -918,6 +922,7 @@ __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restric
   const float bc1 = -expm1f(stepf * log_b1), sqrt_bc2 = sqrtf(-expm1f(stepf * log_b2));
   const float lr = eta_min + (lr0 - eta_min) * 0.5f * (1.0f + cospif((float)sched / (float)t_max));
   if (gnorm_sq) coef = fminf(1.0f, clip / (nrm + 1e-6f));
+  const float one_minus_decay = 1.0f - fminf(ema_decay, (1.0f + stepf) / (10.0f + stepf));
   int r = 0;
   while (r + 1 < rg.count && (int)blockIdx.x >= rg.first_block[r + 1]) ++r;  // this workgroup's range (wave-uniform)
   const long lo = rg.lo[r], hi = lo + rg.n[r];
@@ -932,6 +937,10 @@ __global__ void adamw_sched_kernel(float* __restrict__ p, const float* __restric
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
+    if constexpr (EMA) {
+      const float sh = ema[i];
+      ema[i] = sh - (sh - pi) * one_minus_decay;
+    }
   }
 }
 __global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, float alpha, float beta, long n) {
@@ -1241,15 +1250,22 @@ int adamw_step_ranges(float* p, const float* g, float* m, float* v, const long* 
   }
   rg.first_block[count] = used;
   rg.count = count;
-  hipLaunchKernelGGL(adamw_sched_kernel, dim3(used), dim3(256), 0, s, p, g, m, v, rg, gnorm_sq, h.clip, h.lr0, h.eta_min, h.t_max, h.b1, h.b2, (float)log((double)h.b1),
-                     (float)log((double)h.b2), h.eps, h.wd, state_in, state_out, h.max_grad_norm, nonfinite, gnorm_out, leader ? 1 : 0);
+  if (h.ema)
+    hipLaunchKernelGGL(adamw_sched_kernel<true>, dim3(used), dim3(256), 0, s, p, g, m, v, rg, gnorm_sq, h.clip, h.lr0, h.eta_min, h.t_max, h.b1, h.b2,
+                       (float)log((double)h.b1), (float)log((double)h.b2), h.eps, h.wd, state_in, state_out, h.max_grad_norm, nonfinite, gnorm_out, leader ? 1 : 0,
+                       h.ema, h.ema_decay);
+  else
+    hipLaunchKernelGGL(adamw_sched_kernel<false>, dim3(used), dim3(256), 0, s, p, g, m, v, rg, gnorm_sq, h.clip, h.lr0, h.eta_min, h.t_max, h.b1, h.b2,
+                       (float)log((double)h.b1), (float)log((double)h.b2), h.eps, h.wd, state_in, state_out, h.max_grad_norm, nonfinite, gnorm_out, leader ? 1 : 0,
+                       (float*)nullptr, 0.0f);
   V4H_CHECK_LAUNCH("adamw_sched");
   return V4H_OK;
 }
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
-                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s) {
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s, float* ema,
+                     float ema_decay) {
   const long lo = 0;
-  const AdamwHyper h{clip, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm};
+  const AdamwHyper h{clip, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm, ema, ema_decay};
   return adamw_step_ranges(p, g, m, v, &lo, &n, 1, h, gnorm_sq, state_in, state_out, nonfinite, gnorm_out, true, s);
 }
 int slab_reduce(const float* slab, int nz, long n, float* out, hipStream_t s, bool set) {

@@ -88,13 +88,14 @@ int adamw_step(float* p, const float* g, float* m, float* v, long n, const float
                float bc1, float bc2, int* nonfinite, hipStream_t s);
 constexpr int ADAM_MAX_RANGES = 12;
 struct AdamRanges { long lo[ADAM_MAX_RANGES], n[ADAM_MAX_RANGES]; int first_block[ADAM_MAX_RANGES + 1]; int count; };
-struct AdamwHyper { float clip, lr0, eta_min; int t_max; float b1, b2, eps, wd, max_grad_norm; };
+struct AdamwHyper { float clip, lr0, eta_min; int t_max; float b1, b2, eps, wd, max_grad_norm; float* ema = nullptr; float ema_decay = 0.f; };  // ema: optional shadow parameters (flat, like p)
 // over `count` element ranges [lo, lo + n) of the flat buffers in one launch; leader: the launch of a step that writes state_out / counts a skip
 int adamw_step_ranges(float* p, const float* g, float* m, float* v, const long* lo, const long* n, int count, const AdamwHyper& h, const float* gnorm_sq,
                       const int* state_in, int* state_out, int* nonfinite, float* gnorm_out, bool leader, hipStream_t s);
 // the same with the step index and the cosine-schedule position on the device (state_in / state_out: 4 ints each, distinct)
 int adamw_step_sched(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float clip, float lr0, float eta_min, int t_max, float b1, float b2,
-                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s);
+                     float eps, float wd, const int* state_in, int* state_out, float max_grad_norm, int* nonfinite, float* gnorm_out, hipStream_t s,
+                     float* ema = nullptr, float ema_decay = 0.f);
 int axpby(float* out, const float* a, const float* b, float alpha, float beta, long n, hipStream_t s);  // out = alpha*a + beta*b (a may alias out)
 int rk4_combine(float* y, const float* k1, const float* k2, const float* k3, const float* k4, float h, long n, hipStream_t s);
 

@@ -573,7 +573,7 @@ extern "C" int32_t v4h_vit_update_ahead(const v4h_plan* p, int32_t B, const void
     RUN(side_wait_main(*p, c.s));
     st = p->side;
   }
-  const AdamwHyper h{max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm};
+  const AdamwHyper h{max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, max_grad_norm, nullptr, 0.f};
   for (int stage = 0; stage <= p->depth; ++stage) {
     std::vector<long> lo, n;
     auto range = [&](int i0, int i1) { lo.push_back((long)offsets[i0]); n.push_back((long)(offsets[i1] - offsets[i0])); };
@@ -1118,6 +1118,15 @@ extern "C" int32_t v4h_adamw_step_sched(float* p, const float* g, float* m, floa
   V4H_CHECK_ARG(state_in != state_out, "adamw_step_sched: d_state_in and d_state_out must be distinct (every thread reads the one, one thread writes the other)");
   return adamw_step_sched(p, g, m, v, n, gnorm_sq, max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out, max_grad_norm, nonfinite, gnorm_out,
                           (hipStream_t)s);
+}
+extern "C" int32_t v4h_adamw_step_sched_ema(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr0, float eta_min,
+                                            int32_t t_max, float b1, float b2, float eps, float wd, const int32_t* state_in, int32_t* state_out, float max_grad_norm,
+                                            void* s, int32_t* nonfinite, float* gnorm_out, float* ema, float ema_decay) {
+  V4H_CHECK_ARG(p && g && m && v && n > 0 && state_in && state_out && t_max > 0 && ema, "adamw_step_sched_ema: bad argument");
+  V4H_CHECK_ARG(state_in != state_out, "adamw_step_sched_ema: d_state_in and d_state_out must be distinct");
+  V4H_CHECK_ARG(ema_decay >= 0.0f && ema_decay <= 1.0f, "Decay must be between 0 and 1");  // torch_ema's own check and text
+  return adamw_step_sched(p, g, m, v, n, gnorm_sq, max_norm, lr0, eta_min, t_max, b1, b2, eps, wd, state_in, state_out, max_grad_norm, nonfinite, gnorm_out,
+                          (hipStream_t)s, ema, ema_decay);
 }
 extern "C" int32_t v4h_axpby(float* out, const float* a, const float* b, float alpha, float beta, int64_t n, void* s) {
   V4H_CHECK_ARG(out && a && b && n > 0, "axpby: bad argument");

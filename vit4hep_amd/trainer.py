@@ -10,6 +10,11 @@ with configs/training/default.yaml) on flat HBM buffers, without autograd and wi
 
 Loss and gradient norm come back as 0-dim device tensors; call ``check_finite`` (or .item()) when the host needs them.
 
+EMA (``ema_decay=...``, the reference's ``ema: true`` + ``training.ema_decay``, base_experiment.py:127-134,593-594): the shadow parameters are updated inside
+the AdamW pass (one more f32 stream); ``ema_state_dict()`` is ``torch_ema.ExponentialMovingAverage.state_dict()``'s layout and ``average_parameters()`` its
+context manager (validation under the averaged weights, :630-631).  Optimizers other than AdamW and schedulers other than CosineAnnealingLR
+(base_experiment.py:329-431) are not this class's fused update: they raise and point at the autograd route, where any torch optimizer works.
+
 Checkpoints: ``state_dict()`` / ``load_state_dict()`` speak the layout of the reference's checkpoint file (``{"model", "optimizer", "scheduler", "ema"}``,
 base_experiment.py:661-677): the "optimizer" entry is a ``torch.optim.AdamW.state_dict()`` (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in
 ``model.parameters()`` order, one param group), the "scheduler" entry a ``CosineAnnealingLR.state_dict()`` - so a run of this trainer can be continued by the
@@ -39,8 +44,19 @@ class CFMTrainer:
     MIN_STEP_SKIP = 1000  # base_experiment.py:31
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None,
-                 nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0, pipeline_update=None):
+                 nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0, pipeline_update=None, ema_decay=None,
+                 optimizer="AdamW", scheduler="CosineAnnealingLR"):
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
+
+        # training.optimizer / training.scheduler of the reference (base_experiment.py:329-431: Adam, AdamW, RAdam, Lion, ScheduleFree; OneCycleLR,
+        # CosineAnnealingLR, ReduceLROnPlateau, ...).  The fused update IS AdamW + CosineAnnealingLR (configs/training/default.yaml); anything else trains
+        # through the autograd node (vit4hep_amd.dropin + the reference's own _init_optimizer / _init_scheduler), where every torch optimizer works.
+        if optimizer != "AdamW":
+            raise NotImplementedError(f"CFMTrainer: optimizer {optimizer!r} is not the fused update (AdamW only); use the autograd route "
+                                      "(model.net through vit4hep_amd.dropin and the reference's _init_optimizer, experiments/base_experiment.py:329-372)")
+        if scheduler != "CosineAnnealingLR":
+            raise NotImplementedError(f"CFMTrainer: scheduler {scheduler!r} is not the fused update (CosineAnnealingLR only); use the autograd route "
+                                      "(the reference's _init_scheduler, experiments/base_experiment.py:390-431)")
 
         self.model = model
         self.net = model._core() if hasattr(model, "_core") else _unwrap(model.net)  # _core() (re)binds the wrapper's geometry to the net
@@ -67,6 +83,17 @@ class CFMTrainer:
         # between two steps.  Single rank, no CUDA-graph capture, no embedding mappers.
         self.pipeline_update = (os.environ.get("V4H_PIPELINE_UPDATE") == "1") if pipeline_update is None else bool(pipeline_update)
         self._ahead = None  # (workspace pointer, batch) the operand copies of the update in flight were made for
+        # EMA of the parameters (torch_ema.ExponentialMovingAverage(model.parameters(), decay): the shadow starts as a copy of the parameters)
+        if ema_decay is not None and not (0.0 <= float(ema_decay) <= 1.0):
+            raise ValueError("Decay must be between 0 and 1")  # torch_ema's text
+        self.ema_decay = float(ema_decay) if ema_decay is not None else None
+        self.flat_ema = None
+        self._ema_collected = None
+        if self.ema_decay is not None and self.pipeline_update:
+            raise NotImplementedError("CFMTrainer: ema_decay with pipeline_update is not built (the pipelined update kernel has no shadow stream)")
+        if self.pipeline_update and os.environ.get("V4H_STEP_GRAPH") == "1":
+            raise ValueError("CFMTrainer: pipeline_update and V4H_STEP_GRAPH are mutually exclusive (a captured step replays the in-line update, which does "
+                             "not refresh the operand copies a pipelined update prepares)")
         # The reference raises on a non-finite gradient norm BEFORE optimizer.step(), also without clipping (max_norm = inf; base_experiment.py:573-585).
         # Here the update kernel skips such a step on the device and bumps a sticky counter - and while that counter is non-zero it skips (and counts)
         # EVERY later update too, so no update is ever applied with a shifted Adam / LR-schedule index.  The host looks at the counter every
@@ -100,6 +127,9 @@ class CFMTrainer:
                 self.p_views.append(view)
                 self.g_views.append(self.flat_g[o : o + p.numel()].view_as(p))
         self.params = params
+        if getattr(self, "ema_decay", None) is not None:
+            old = getattr(self, "flat_ema", None)
+            self.flat_ema = old.to(dev) if old is not None and old.numel() == off else self.flat_p.clone()
         # contiguous gradient slice of each backward stage (include/vit4hep_hip.h: stage 0 final layer, 1+j block depth-1-j, last embedders)
         depth = int(self.net.depth)
         blk0 = 11
@@ -330,7 +360,7 @@ class CFMTrainer:
         self.iteration += 1
         st_in, st_out = self._state[self._cur], self._state[self._cur ^ 1]
         capturing = getattr(self, "_in_capture", False)
-        if self.pipeline_update and not capturing and not collectives_enabled() and self._ws is not None and self._last_B is not None:
+        if self.pipeline_update and not capturing and not self.use_graph and not collectives_enabled() and self._ws is not None and self._last_B is not None:
             hyper = (self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations, self.betas[0], self.betas[1], self.eps, self.wd,
                      skip_above)
             update_ahead(self.net, self.p_views, (self.flat_p, self.flat_g, self.flat_m, self.flat_v), self._offsets_c, self._ws, self._last_B, self.gnorm_sq,
@@ -341,14 +371,16 @@ class CFMTrainer:
             out_loss = loss
             if self.nonfinite_check_every > 0 and self.step_count % self.nonfinite_check_every == 0:
                 self.raise_if_nonfinite()
-            return out_loss, self.gnorm
-        _lib.check(
-            lib.v4h_adamw_step_sched(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total,
-                                     _lib.ptr(self.gnorm_sq), self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations,
-                                     self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite),
-                                     _lib.ptr(self.gnorm)),
-            "v4h_adamw_step_sched",
-        )
+            # The norm's root is written by the update's first launch on the library's SIDE stream, which the current stream does not wait for: hand back the
+            # squared norm's root computed on the current stream instead (one 1-element launch, same value: sqrt of the very scalar the update reads).
+            return out_loss, torch.sqrt(self.gnorm_sq)
+        args = (_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.flat_m), _lib.ptr(self.flat_v), self.total, _lib.ptr(self.gnorm_sq),
+                self.clip if self.clip is not None else float("inf"), self.lr, self.eta_min, self.iterations, self.betas[0], self.betas[1], self.eps, self.wd,
+                _lib.ptr(st_in), _lib.ptr(st_out), skip_above, s, _lib.ptr(self.nonfinite), _lib.ptr(self.gnorm))
+        if self.flat_ema is not None:
+            _lib.check(lib.v4h_adamw_step_sched_ema(*args, _lib.ptr(self.flat_ema), self.ema_decay), "v4h_adamw_step_sched_ema")
+        else:
+            _lib.check(lib.v4h_adamw_step_sched(*args), "v4h_adamw_step_sched")
         if capturing:  # a replayed graph has fixed pointers: copy the new counters back instead of swapping the two buffers
             st_in.copy_(st_out)
         else:
@@ -439,9 +471,67 @@ class CFMTrainer:
         """The trainer's half of the reference's checkpoint file: ``{"optimizer": ..., "scheduler": ...}`` (add ``"model": model.state_dict()``)."""
         return {"optimizer": self.optimizer_state_dict(), "scheduler": self.scheduler_state_dict()}
 
+    def ema_state_dict(self):
+        """``torch_ema.ExponentialMovingAverage.state_dict()`` of this run (base_experiment.py:674): decay, num_updates (= applied optimizer steps: the
+        reference calls ema.update() exactly once per applied update), shadow_params in ``model.parameters()`` order, collected_params."""
+        if self.flat_ema is None:
+            return None
+        self._check_alias()
+        n = self.sync_counters()["optimizer_steps"] - getattr(self, "_ema_step0", 0)
+        shadow = []
+        for i in self._torch_param_order():
+            o, k = self.offsets[i], self.params[i].numel()
+            shadow.append(self.flat_ema[o : o + k].view_as(self.params[i]).clone())
+        return {"decay": self.ema_decay, "num_updates": n, "shadow_params": shadow, "collected_params": None}
+
+    def load_ema_state_dict(self, sd):
+        if self.flat_ema is None:
+            raise RuntimeError("CFMTrainer: constructed without ema_decay")
+        self.finish()
+        self._check_alias()
+        order = self._torch_param_order()
+        if len(sd["shadow_params"]) != len(order):
+            raise ValueError("shadow_params must have the same length as the parameters")  # torch_ema's check
+        self.ema_decay = float(sd["decay"])
+        for k, i in enumerate(order):
+            o, n = self.offsets[i], self.params[i].numel()
+            self.flat_ema[o : o + n].view_as(self.params[i]).copy_(sd["shadow_params"][k])
+        # the kernel derives torch_ema's warm-up count from the optimizer's step counter: remember the difference (0 for a file written by this class or
+        # by the reference, where both count the same updates)
+        self._ema_step0 = self.sync_counters()["optimizer_steps"] - int(sd["num_updates"] or 0)
+        if self._ema_step0 != 0:
+            raise NotImplementedError("CFMTrainer.load_ema_state_dict: num_updates differs from the optimizer's step count (the fused kernel takes the EMA "
+                                      "warm-up position from the optimizer step); load the optimizer state first, or use the autograd route")
+
+    class _Averaged:
+        def __init__(self, tr):
+            self.tr = tr
+
+        def __enter__(self):  # torch_ema: store(), copy_to()
+            tr = self.tr
+            tr.finish()
+            tr._check_alias()
+            tr._ema_collected = tr.flat_p.clone()
+            tr.flat_p.copy_(tr.flat_ema)
+            tr.net.weights_epoch += 1
+            return tr
+
+        def __exit__(self, *exc):  # torch_ema: restore()
+            tr = self.tr
+            tr.flat_p.copy_(tr._ema_collected)
+            tr._ema_collected = None
+            tr.net.weights_epoch += 1
+            return False
+
+    def average_parameters(self):
+        """``with trainer.average_parameters(): validate()`` - the model runs with the shadow parameters inside the block (base_experiment.py:630-631)."""
+        if self.flat_ema is None:
+            raise RuntimeError("CFMTrainer: constructed without ema_decay")
+        return CFMTrainer._Averaged(self)
+
     def checkpoint(self):
-        """The whole file the reference's ``_save_model`` writes (base_experiment.py:667-675); no EMA here."""
-        return {"model": self.model.state_dict(), **self.state_dict(), "ema": None}
+        """The whole file the reference's ``_save_model`` writes (base_experiment.py:667-675)."""
+        return {"model": self.model.state_dict(), **self.state_dict(), "ema": self.ema_state_dict()}
 
     def load_state_dict(self, sd):
         """Continue from ``state_dict()`` / ``checkpoint()`` of this class, or from the "optimizer" / "scheduler" entries written by the reference's
@@ -491,6 +581,8 @@ class CFMTrainer:
             new[1] = applied
         for t in self._state:
             t.copy_(torch.tensor(new, dtype=torch.int32))
+        if sd.get("ema") is not None and self.flat_ema is not None:
+            self.load_ema_state_dict(sd["ema"])
         self.nonfinite.zero_()
         self.step_count = new[0]
         self._graph = None  # a captured step (use_graph) has the old hyper-parameters as kernel arguments: capture again
