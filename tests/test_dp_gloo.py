@@ -107,3 +107,33 @@ def _dp_equivalence_job(rank, world, out):
 def test_sum_of_scaled_local_grads_equals_global_mean_grad():
     res = _run(_dp_equivalence_job)
     assert set(res) == {0, 1} and max(res.values()) < 1e-4, res
+
+
+def _bucket_bf16_job(rank, world, out):
+    from vit4hep_amd.parallel import BucketReducer
+
+    torch.manual_seed(rank)
+    flat = torch.randn(1000)
+    mine = flat.clone()
+    red = BucketReducer(flat, compress="bf16")
+    for lo, hi in [(900, 1000), (500, 900), (100, 500), (0, 100)]:
+        red.reduce_slice(lo, hi)
+    red.finish()
+    gathered = [torch.zeros(1000) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    exact = sum(gathered)
+    # what the compressed path is defined to give: every rank's slice rounded to bf16, summed, the sum rounded to bf16 again, kept as f32
+    model = sum(g.to(torch.bfloat16).float() for g in gathered).to(torch.bfloat16).float()
+    assert flat.dtype == torch.float32 and torch.equal(flat, model), float((flat - model).abs().max())
+    assert float((flat - exact).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())  # bf16 rounding of the f32 path
+    out[rank] = True
+
+
+def test_bucket_reducer_bf16_all_reduce_keeps_an_f32_master_gradient():
+    """compress="bf16" (reference gradient exchange experiments/base_experiment.py:161-167): half the bytes on the wire, the result
+    equals the f32 sum to bf16 rounding and lands in the f32 buffer the optimizer reads."""
+    assert _run(_bucket_bf16_job) == {0: True, 1: True}
+    with pytest.raises(ValueError):
+        from vit4hep_amd.parallel import BucketReducer
+
+        BucketReducer(torch.zeros(4), compress="fp8")

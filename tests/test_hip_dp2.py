@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, mode, steps, out):
+def _rank_main(rank, world, port, mode, steps, out, grad_allreduce=None):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
     import torch.distributed as dist
 
@@ -41,8 +41,8 @@ def _rank_main(rank, world, port, mode, steps, out):
         noise = [O.synthetic_noise(cfg, B, g) for _ in range(steps)]
         lo, hi = shard_rows(B, rank, world)
         model = U.build_models(cfg, mode, O.golden_fill(cfg))
-        tr = CFMTrainer(model, iterations=20)
-        assert collectives_enabled()
+        tr = CFMTrainer(model, iterations=20, grad_allreduce=grad_allreduce)
+        assert collectives_enabled() and tr.reducer.compress == (grad_allreduce if grad_allreduce == "bf16" else None)
         losses, norms = [], []
         for t, x0 in noise:
             l, n = tr.step(x[lo:hi].to(U.DEV), c[lo:hi].to(U.DEV), t[lo:hi].to(U.DEV), x0[lo:hi].to(U.DEV))
@@ -54,19 +54,21 @@ def _rank_main(rank, world, port, mode, steps, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_two_rank_hip_trainer_matches_single_process_on_the_whole_batch(mode):
+@pytest.mark.parametrize("mode,grad_allreduce", [("f32", None), ("bf16", None), ("f32", "bf16")])
+def test_two_rank_hip_trainer_matches_single_process_on_the_whole_batch(mode, grad_allreduce):
+    """grad_allreduce="bf16" (round 5; f32 arithmetic mode so that the compression is the only rounding in play): five steps, the trajectory within 1e-3 of the
+    single-process run, the weights to bf16 rounding of the f32 exchange."""
     import torch.multiprocessing as mp
 
     from oracle import vit_cfm_oracle as O
     from tests import hiputil as U
     from vit4hep_amd.trainer import CFMTrainer
 
-    steps = 3
+    steps = 5 if grad_allreduce else 3
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, mode, steps, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, mode, steps, out, grad_allreduce)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -85,13 +87,13 @@ def test_two_rank_hip_trainer_matches_single_process_on_the_whole_batch(mode):
         ref_l.append(float(l))
         ref_n.append(float(n))
     sd = model.state_dict()
-    tol = 1e-5 if mode == "f32" else 2e-3
+    tol = 1e-3 if grad_allreduce else (1e-5 if mode == "f32" else 2e-3)
     for r in (0, 1):
         losses, norms, w = out[r]
         assert np.allclose(losses, ref_l, rtol=tol), (r, losses, ref_l)   # the loss is averaged over the ranks
         assert np.allclose(norms, ref_n, rtol=10 * tol), (r, norms, ref_n)  # norm of the all-reduced gradient
         for k, v in w.items():
-            assert U.rel_err(torch.from_numpy(v), sd[k]) < (1e-4 if mode == "f32" else 5e-3), (r, k)
+            assert U.rel_err(torch.from_numpy(v), sd[k]) < (5e-3 if (grad_allreduce or mode == "bf16") else 1e-4), (r, k)
     for k in out[0][2]:  # and both ranks hold the same weights
         assert np.array_equal(out[0][2][k], out[1][2][k]) or U.rel_err(torch.from_numpy(out[0][2][k]), torch.from_numpy(out[1][2][k])) < 1e-6, k
 

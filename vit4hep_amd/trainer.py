@@ -45,7 +45,7 @@ class CFMTrainer:
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, group=None,
                  nonfinite_check_every=50, max_grad_norm=None, clip_grad_value=None, eta_min=0.0, pipeline_update=None, ema_decay=None,
-                 optimizer="AdamW", scheduler="CosineAnnealingLR"):
+                 optimizer="AdamW", scheduler="CosineAnnealingLR", grad_allreduce=None):
         from .experiments.calochallenge.calochallenge_cfm.model import _unwrap
 
         # training.optimizer / training.scheduler of the reference (base_experiment.py:329-431: Adam, AdamW, RAdam, Lion, ScheduleFree; OneCycleLR,
@@ -101,6 +101,8 @@ class CFMTrainer:
         # updates: parameters, moments and step index are then exactly those of the last finite step, as after the reference's raise.  (All ranks see
         # the same all-reduced gradient norm, hence the same counter.)
         self.nonfinite_check_every = int(nonfinite_check_every)
+        # gradient all-reduce of the data-parallel path: f32 (default) or "bf16" (half the bytes over xGMI, f32 master gradients; parallel.BucketReducer)
+        self.grad_allreduce = grad_allreduce if grad_allreduce is not None else os.environ.get("V4H_GRAD_ALLREDUCE")
         self._flatten()
 
     # ---------------------------------------------------------------------------------------------- flat buffers
@@ -141,7 +143,7 @@ class CFMTrainer:
         self.stage_slices.append(bounds(0, blk0))
         self._offsets_c = (_lib.C.c_int64 * (len(params) + 1))(*self.offsets, self.total)
         self._last_B = None
-        self.reducer = BucketReducer(self.flat_g, self.group)
+        self.reducer = BucketReducer(self.flat_g, self.group, compress=getattr(self, "grad_allreduce", None))
         self.comm_reserve_cus = int(os.environ.get("V4H_COMM_RESERVE_CUS", "0"))  # multiple of 8 in [0, 64]
         self.stage_events = None
         self._scal = torch.zeros(4, dtype=torch.float32, device=dev)  # loss | squared gradient norm | gradient norm of the step in progress
