@@ -20,7 +20,7 @@ import sys
 import time
 
 # More hardware queues than HIP's default 4, before the runtime starts: the weight-gradient stream, torch's communication stream
-# and RCCL's own streams must not be multiplexed onto the compute stream's queue (the library also gives its
+# and RCCL's own streams must not be multiplexed onto the compute stream's queue (docs/history_r01-r04.md section 6; the library also gives its
 # side stream its own priority class, which is what makes the overlap robust when this variable is not set).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -147,7 +147,7 @@ OP_RATE_SETS = 6  # buffer sets each timed operator rotates over: with >= 300 MB
 
 def _time_rotating(calls, reps):
     """Mean HIP-event time per call of `calls[k % len(calls)]()`: consecutive calls use different buffer sets, so operands and output lines are cold (as they are
-    inside the update step; a loop over ONE buffer set re-uses cache-resident output lines and reads 6-9 % fast - DESIGN.md section 5 item 5)."""
+    inside the update step; a loop over ONE buffer set re-uses cache-resident output lines and reads 6-9 % fast - docs/history_r01-r04.md section 5 item 5)."""
     for k in range(len(calls)):
         calls[k]()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

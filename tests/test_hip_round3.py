@@ -52,7 +52,7 @@ def test_update_step_gradients_at_batch_32_match_the_oracle():
     grads = U.named_grads(model)
     for k, r in ref.items():
         if k.endswith("attn.qkv.bias"):
-            continue  # (the key third is analytically zero: rounding noise on both sides)
+            continue  # (the key third is analytically zero: rounding noise on both sides; docs/history_r01-r04.md section 2)
         assert U.rms_err(grads[k], r) < 3e-2, (k, U.rms_err(grads[k], r))
 
 

@@ -310,7 +310,7 @@ def test_operand_copies_ahead_of_the_forward_change_nothing():
     assert np.allclose(runs[0][0], runs[1][0], rtol=2e-3), (runs[0][0], runs[1][0])  # bf16 mode: atomically summed tensors vary in the last bit run to run
     for k, v in runs[1][1].items():
         got = runs[0][1][k]
-        if k.endswith("attn.qkv.bias"):  # the key third's gradient is analytically zero: rounding noise that Adam turns into +-lr per step
+        if k.endswith("attn.qkv.bias"):  # the key third's gradient is analytically zero: rounding noise that Adam turns into +-lr per step (docs/history_r01-r04.md section 2)
             D = cfg.hidden_dim
             got, v = torch.cat([got[:D], got[2 * D :]]), torch.cat([v[:D], v[2 * D :]])
         assert U.rel_err(got, v) < 5e-3, k
@@ -318,7 +318,7 @@ def test_operand_copies_ahead_of_the_forward_change_nothing():
 
 def test_whole_step_hipgraph_replays_the_update():
     """Opt-in (use_graph / V4H_STEP_GRAPH=1): noise, trajectory, forward, two-stream backward, norm and AdamW captured once and replayed - possible because the
-    optimizer's step index and LR position live on the device.  (Slower than the eager launch sequence on ROCm 7.2: DESIGN.md; kept as a tested option.)"""
+    optimizer's step index and LR position live on the device.  (Slower than the eager launch sequence on ROCm 7.2: docs/history_r01-r04.md section 5; kept as a tested option.)"""
     from vit4hep_amd.trainer import CFMTrainer
 
     cfg = O.ds2(2)
@@ -373,7 +373,7 @@ def test_pipelined_update_gives_the_in_line_trajectory(mode):
     D = cfg.hidden_dim
     for k, v in runs[0][1].items():
         got = runs[1][1][k]
-        if k.endswith("attn.qkv.bias"):  # the key third has an analytically zero gradient: Adam-normalised rounding noise on both sides
+        if k.endswith("attn.qkv.bias"):  # the key third has an analytically zero gradient: Adam-normalised rounding noise on both sides (docs/history_r01-r04.md section 2)
             keep = torch.cat([torch.arange(0, D), torch.arange(2 * D, 3 * D)]).to(v.device)
             got, v = got[keep], v[keep]
         assert U.rel_err(got, v) < (1e-3 if mode == "f32" else 5e-3), k

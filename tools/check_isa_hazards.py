@@ -1,4 +1,4 @@
-"""Build-time guard for two gfx950 hazards found in round 3 ("What round 3 found" 5a; csrc/v4h_attention_dense.h:12-14,235-236):
+"""Build-time guard for two gfx950 hazards found in round 3 (docs/history_r01-r04.md section 5, "What round 3 found" 5a; csrc/v4h_attention_dense.h:12-14,235-236):
 
   1. `v_mfma_f32_16x16x16_*` accumulating straight onto the result of a 16x16x32 MFMA came out wrong in two of four registers whenever the pair was
      scheduled back to back.  The product library uses no K = 16 MFMA at all: the check is that none appears in its device code.

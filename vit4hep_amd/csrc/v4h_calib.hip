@@ -1,5 +1,5 @@
 // Box calibration for bench.py (not on the hot path): what THIS card, at its clocks today, does on (a) a loop of nothing but bf16 MFMAs on random
-// operands and (b) a 16-byte-per-lane streaming copy.  Box classes of the pool differ by 2-4 % in step rate; the two figures go
+// operands and (b) a 16-byte-per-lane streaming copy.  Box classes of the pool differ by 2-4 % in step rate (docs/history_r01-r04.md section 5); the two figures go
 // into the bench line next to the step rate so that rates measured on different boxes can be compared.
 #include "v4h_common.h"
 #include "v4h_ops.h"

@@ -1026,8 +1026,7 @@ int unpad_f32(const float* src, int ld_src, float* dst, int R, int C, hipStream_
 }
 int patchify(Mode m, const float* vox, void* xp, int B, const PatchGeom& g, int P, int Ppad, hipStream_t s) {
   const size_t slab_bytes = (size_t)g.p1 * g.A * g.R * 4;
-  static const bool staged = !(getenv("V4H_PATCHIFY_LDS") && getenv("V4H_PATCHIFY_LDS")[0] == '0');
-  if (staged && Ppad % 8 == 0 && slab_bytes <= 48 * 1024 && ((uintptr_t)xp % 16) == 0 && B <= 65535) {  // regular grid through LDS (one launch, padding included)
+  if (Ppad % 8 == 0 && slab_bytes <= 48 * 1024 && ((uintptr_t)xp % 16) == 0 && B <= 65535) {  // regular grid through LDS (one launch, padding included)
     if (m == MODE_BF16) hipLaunchKernelGGL(patchify_slab_kernel<bf16>, dim3(g.l, B), dim3(256), slab_bytes, s, vox, (bf16*)xp, g, P, Ppad);
     else hipLaunchKernelGGL(patchify_slab_kernel<float>, dim3(g.l, B), dim3(256), slab_bytes, s, vox, (float*)xp, g, P, Ppad);
     V4H_CHECK_LAUNCH("patchify/slab");

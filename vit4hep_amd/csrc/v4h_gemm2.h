@@ -1,6 +1,6 @@
 // Second-generation bf16 contraction for the token-sized Linears of the ViT path (same operand conventions and the same
 // dense, swizzled LDS images as v4h_gemm.h; reference nn/vit.py: qkv :416, proj :420, timm Mlp fc1/fc2 :317-322 and their
-// dgrad / wgrad).  What changed, and why:
+// dgrad / wgrad).  What changed, and why (docs/history_r01-r04.md section 5, round 2):
 //
 //   * ONE 8-wave workgroup per CU on a 256 x 160 tile (wave tile 64 x 80 as before): 98 instead of 71 FLOP per staged byte -
 //     the CU's global->LDS intake (about 70 GB/s per CU) is what bounded the 128 x 160 / two-workgroup structure.
@@ -25,7 +25,7 @@
 //   * ping-pong (the default wherever the kernel is used): per SIMD one wave runs a LOAD slot (all 18 fragment reads of a stage, its share of
 //     the DMA of the stage two ahead, at a seam the previous tile's epilogue) while its partner runs a MATRIX slot (the 40 MFMAs of the stage
 //     it loaded one slot earlier) - half 0 (waves 0..3) load, matrix, barrier; half 1 matrix of the previous stage, load, barrier: one barrier
-//     per stage, the halves in anti-phase by construction.  DESIGN.md section 5 "What round 2 found" 8, profiles/r02_gemm2_pingpong_timeline.txt.
+//     per stage, the halves in anti-phase by construction.  docs/history_r01-r04.md section 5 "What round 2 found" 8, profiles/r02_gemm2_pingpong_timeline.txt.
 #pragma once
 #include "v4h_gemm.h"
 

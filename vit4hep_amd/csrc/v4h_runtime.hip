@@ -97,9 +97,7 @@ static int side_init(const v4h_plan& p) {
   // The events only order the two streams of this device against each other; nobody inspects them from the host, so recording one
   // needs no system-scope release (an L2 write-back + ~6 us bubble in front of the next kernel of the recording stream, 30 times per
   // step: 180.1 -> 182.8 steps/s).  The kernels' own agent-scope release at their end is what the other stream's kernels need.
-  unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
-  const char* ef = getenv("V4H_EVENT_SYSFENCE");
-  if (ef && ef[0] == '1') evflags = hipEventDisableTiming;
+  const unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
   for (int i = 0; i < 8; ++i)
     if (hipEventCreateWithFlags(&p.ev[i], evflags) != hipSuccess) { v4h_set_error("cannot create event"); return V4H_ERR_HIP; }
   for (int i = 0; i < 4; ++i)

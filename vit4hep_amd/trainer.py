@@ -312,7 +312,7 @@ class CFMTrainer:
         """The whole update - noise, trajectory, forward, two-stream backward, norm, AdamW - captured once into a hipGraph and replayed: the optimizer's
         step index and LR position live on the device (v4h_adamw_step_sched), so no kernel argument changes between replays; only t (sampled on the host
         generator like the reference, models/base_model.py:209-211) is copied into its static buffer first.  The returned tensors are the graph's own
-        (overwritten by the next replay).  Opt-in (V4H_STEP_GRAPH=1 / use_graph): measured against the eager launch sequence in DESIGN.md."""
+        (overwritten by the next replay).  Opt-in (V4H_STEP_GRAPH=1 / use_graph): measured against the eager launch sequence in docs/history_r01-r04.md section 5."""
         self._check_alias()
         x = _lib.require_cuda(x, "x")
         c = _lib.require_cuda(c, "c")
