@@ -145,6 +145,14 @@ int32_t v4h_plan_residual_storage(const v4h_plan* plan);
 int32_t v4h_vit_backward(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout, void* d_workspace,
                          size_t workspace_bytes, int32_t stage_first, int32_t stage_last, void* stream, const int32_t* d_patch_map, const float* d_pos);
 int32_t v4h_vit_num_backward_stages(const v4h_plan* plan);
+/* One stage of a backward pass issued stage by stage (stages in order 0 ... depth + 1, as v4h_vit_backward(stage, stage)) WITHOUT a join of the library's
+ * two streams behind every stage (ABI 11; the route of the reference's DDP(model.net), experiments/base_experiment.py:161-167, whose bucket hooks fire per
+ * autograd node): `stage_event` (hipEvent_t, optional) is recorded when this stage's gradient tensors are final, on whichever internal stream finishes
+ * them; join != 0 additionally orders `stream` behind everything (what v4h_vit_backward does).  The last stage always joins.  A caller that passes join = 0
+ * must make its stream wait for a stage's event before it reads that stage's gradients. */
+int32_t v4h_vit_backward_stage(const v4h_plan* plan, int32_t B, const void* const* d_params, void* const* d_grads, const float* d_dout, void* d_workspace,
+                               size_t workspace_bytes, int32_t stage, void* stream, const int32_t* d_patch_map, const float* d_pos, void* stage_event,
+                               int32_t join);
 /* The whole backward pass (stages 0 .. depth+1) as ONE call that still lets the caller overlap the gradient all-reduce: stage_events is a
  * host array of v4h_vit_num_backward_stages() hipEvent_t handles; event s is recorded - on whichever internal stream completes them - as
  * soon as the gradient tensors of stage s are final.  A communication stream that waits for event s may reduce that stage's gradients

@@ -257,6 +257,7 @@ def test_pipelined_update_returns_the_norm_of_the_inline_update():
         t, x0 = O.synthetic_noise(cfg, 8, g)
         l0, n0 = tr.step(x, c, t.to(U.DEV), x0.to(U.DEV))
         l1, n1 = tr_p.step(x, c, t.to(U.DEV), x0.to(U.DEV))
-        assert float(n1) == float(n0) and float(l1) == float(l0)  # read immediately, no finish() in between
+        # read immediately, no finish() in between (the two runs sum their squared norms with float atomics: equal to the last bits, not bit for bit)
+        assert abs(float(n1) - float(n0)) <= 1e-6 * float(n0) and abs(float(l1) - float(l0)) <= 1e-6 * float(l0)
     tr_p.finish()
-    assert torch.equal(tr.flat_p, tr_p.flat_p)
+    assert float((tr.flat_p - tr_p.flat_p).abs().max()) <= 1e-6 * float(tr.flat_p.abs().max())

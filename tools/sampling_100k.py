@@ -14,7 +14,7 @@ dev = "cuda:0"
 w = WORKLOADS["ds2"]
 cfg = O.ds2(6)
 model = build_model(w, "bf16", dev).eval()
-fill = {k[4:]: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("net.") and not k.startswith("net.pos_")}
+fill = {k[4:]: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("net.") and k[4:] not in ("pos_x", "pos_y", "pos_z")}
 T, P = tokens_and_patch_dim(w)
 flops = fwd_flops_per_sample(T, P, w["depth"], K=w["cond"])
 g = torch.Generator().manual_seed(5)

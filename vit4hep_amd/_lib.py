@@ -71,6 +71,7 @@ SIGNATURES = {
     "v4h_plan_residual_storage": (_i32, [_vp]),
     "v4h_vit_backward": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _i32, _vp, _vp, _vp]),
     "v4h_vit_backward_events": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _vp, _vp, _vp, _pp]),
+    "v4h_vit_backward_stage": (_i32, [_vp, _i32, _pp, _pp, _vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _i32]),
     "v4h_vit_num_backward_stages": (_i32, [_vp]),
     "v4h_energy_plan_create": (_i32, [C.POINTER(V4HEnergyConfig), _pp]),
     "v4h_energy_plan_destroy": (None, [_vp]),

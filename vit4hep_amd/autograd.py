@@ -219,24 +219,66 @@ STAGE_LOG = None  # tests: a list that receives ("stage", s) when backward stage
 class _Pass:
     """State shared by the nodes of one forward / backward pass."""
 
-    __slots__ = ("net", "ws", "patches_io", "params", "grads", "dout", "out", "carrier_grad", "depth", "tables")
+    __slots__ = ("net", "ws", "patches_io", "params", "grads", "dout", "out", "carrier_grad", "depth", "tables", "late", "events")
 
 
 def _stage_param_slices(net, nparams):
-    """Positions in parameter_list() owned by each node: [embedders (+ fine-tuning mappers)], [block 0], ..., [block depth-1], [final layer]."""
+    """Positions in parameter_list() owned by each backward stage: [embedders (+ fine-tuning mappers)], [block 0], ..., [block depth-1], [final layer].
+    The layout is the library's (csrc/v4h_runtime.hip: 11 embedder tensors, 10 per block, 4 of the final layer, mappers behind): checked against the plan."""
     depth = int(net.depth)
+    plan = net._get_plan()
+    if plan.num_stages != depth + 2 or nparams != plan.num_params or nparams < 11 + 10 * depth + 4:
+        raise RuntimeError(f"staged autograd: parameter inventory ({nparams} tensors, depth {depth}) does not match the library's ({plan.num_params} tensors, "
+                           f"{plan.num_stages} backward stages)")
     first = list(range(0, 11)) + list(range(11 + 10 * depth + 4, nparams))
     blocks = [list(range(11 + 10 * i, 11 + 10 * (i + 1))) for i in range(depth)]
     final = list(range(11 + 10 * depth, 11 + 10 * depth + 4))
+    if [plan.shapes[k][0] for k in (final[0], final[2])] != [int(net.final_layer.linear.weight.shape[0]), 2 * int(net.hidden_dim)]:
+        raise RuntimeError("staged autograd: the final layer's tensors are not where the stage map expects them")
     return first, blocks, final
 
 
+def _stage_events(net, n, device):
+    """One torch.cuda.Event per backward stage, created once per network (the library records them: v4h_vit_backward_stage)."""
+    evs = getattr(net, "_stage_evs", None)
+    if evs is None or len(evs) != n or evs[0][1] != torch.device(device):
+        evs = []
+        for _ in range(n):
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(device))  # torch creates the hipEvent_t at the first record
+            evs.append((e, torch.device(device)))
+        net._stage_evs = evs
+    return [e for e, _ in evs]
+
+
 def _run_stage(ps, stage):
+    """One backward stage.  Unshifted chain (some parameters frozen): the call ends with a join of the library's two streams, the stage's gradients are
+    final in stream order when it returns.  Shifted chain (`ps.late`, every parameter trainable - the data-parallel training case): no join, the library
+    records the stage's event, and the gradients are handed to autograd by the NEXT node behind a wait for that event (`_await_stage`)."""
     if STAGE_LOG is not None:
         STAGE_LOG.append(("stage", stage))
     if ps.tables is None:
         ps.tables = (_lib.pointer_table(ps.params), _lib.pointer_table(ps.grads))
-    run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage, tables=ps.tables)
+    if not ps.late:
+        run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage, tables=ps.tables)
+        return
+    plan = ps.net._get_plan()
+    dev = ps.ws.device
+    if ps.events is None:
+        ps.events = _stage_events(ps.net, plan.num_stages, dev)
+    pmap, pos = ps.net.device_tables(dev)
+    last = stage == plan.num_stages - 1
+    with _lib.on_device(ps.ws):
+        _lib.check(
+            _lib.load().v4h_vit_backward_stage(plan.handle, ps.dout.shape[0], ps.tables[0], ps.tables[1], _lib.ptr(ps.dout), _lib.ptr(ps.ws), ps.ws.numel(), stage,
+                                               _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos), None if last else ps.events[stage].cuda_event, 1 if last else 0),
+            "v4h_vit_backward_stage",
+        )
+
+
+def _await_stage(ps, stage):
+    """The current stream waits for the event of an EARLIER stage (long reached: one wait packet, no stall)."""
+    torch.cuda.current_stream(ps.ws.device).wait_event(ps.events[stage])
 
 
 class _StageEmbed(torch.autograd.Function):
@@ -252,7 +294,7 @@ class _StageEmbed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _carrier_grad):
         ps = ctx.ps
-        _run_stage(ps, ps.depth + 1)
+        _run_stage(ps, ps.depth + 1)  # (ends with the full join: block 0's gradients, handed over here on the shifted chain, are final too)
         grads = [ps.grads[i] for i in ctx.idx]
         ps.ws = ps.dout = None
         return (None, None, None, None, None, *grads)
@@ -267,7 +309,10 @@ class _StageBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _carrier_grad):
         ps = ctx.ps
-        _run_stage(ps, 1 + (ps.depth - 1 - ctx.i))
+        st = 1 + (ps.depth - 1 - ctx.i)
+        _run_stage(ps, st)
+        if ps.late:  # ctx.idx are the parameters of the stage BEFORE this one: their event was recorded a whole stage ago
+            _await_stage(ps, st - 1)
         return (None, ps.carrier_grad, None, None, *[ps.grads[k] for k in ctx.idx])
 
 
@@ -310,8 +355,21 @@ def _apply_staged(net, x, t, c, patches_io, params):
         raise RuntimeError(f"input shape {tuple(x.shape)} does not match the network geometry {_vox_shape(net, x_vox.shape[0])}")
     ps = _Pass()
     ps.net, ps.patches_io, ps.params, ps.depth = net, patches_io, [p.detach() for p in params], int(net.depth)
-    ps.ws = ps.grads = ps.dout = ps.out = ps.carrier_grad = ps.tables = None
+    ps.ws = ps.grads = ps.dout = ps.out = ps.carrier_grad = ps.tables = ps.events = None
     first, blocks, final = _stage_param_slices(net, len(params))
+    # Shifted hand-over (round 5): with every parameter trainable each node returns the gradients of the stage that ran BEFORE it in the backward pass -
+    # block i's node those of block i + 1 (block depth-1's those of the final layer), the embedder node its own and block 0's -, so that no stage has to
+    # join the library's weight-gradient stream before it returns: the gradients it hands on were finished a whole stage earlier (an event wait that is long
+    # satisfied).  DDP sees every bucket one stage later and the main stream never stalls for the side stream's tail: 142 -> see profiles/r05_notes.md.
+    ps.late = all(p.requires_grad for p in params) and os.environ.get("V4H_STAGED_LATE", "1") != "0"
+    if ps.late:
+        depth = len(blocks)
+        owned_embed = first + (blocks[0] if depth else final)
+        carrier = _StageEmbed.apply(ps, x_vox, t, c, owned_embed, *[params[i] for i in owned_embed])
+        for i in range(depth):
+            idx = blocks[i + 1] if i + 1 < depth else final
+            carrier = _StageBlock.apply(ps, carrier, i, idx, *[params[k] for k in idx])
+        return _StageFinal.apply(ps, carrier, [])
     carrier = _StageEmbed.apply(ps, x_vox, t, c, first, *[params[i] for i in first])
     for i, idx in enumerate(blocks):
         carrier = _StageBlock.apply(ps, carrier, i, idx, *[params[k] for k in idx])

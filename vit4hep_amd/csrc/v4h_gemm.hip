@@ -85,8 +85,16 @@ inline bool on_ws(const GemmArgs& a, int bit) {
   if (g_kernel == KERNEL_TWO_WG || g_kernel == KERNEL_RING) return false;
   return ((g_ws & bit) != 0 || g_kernel == KERNEL_WS) && v4h_gemm3_eligible(a, WS_K);
 }
+// Column tiles per wave: 3 where the output width allows (fewer LDS fragment reads per MFMA, fewer column slices re-reading the activations), except for
+// the epilogues that need registers of their own - GELU (value + derivative) and DGELU (the saved derivative of the tile) - which spill at 3 x 60 weight
+// registers (11 VGPRs at 256: the DGELU form took 8500 clocks per tile) and run with 2.  V4H_GEMM3_NT pins it (A/B hook).
 template <bool QKS, int EPI> int run_ws(const GemmArgs& a, hipStream_t s, const char* name) {
-  if (v4h_gemm3_pick_nt(a.J) == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
+  static const int pin = env_flag("V4H_GEMM3_NT", 0);
+  int nt = v4h_gemm3_pick_nt(a.J);
+  if ((EPI == EPI_GELU || EPI == EPI_DGELU) && a.J % 32 == 0) nt = 2;
+  if (pin == 2 && a.J % 32 == 0) nt = 2;
+  if (pin == 3 && a.J % 48 == 0) nt = 3;
+  if (nt == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
   return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 2>>(a, s, name);
 }
 

@@ -830,7 +830,8 @@ static int adaln_backward(const Ctx& c, const float* dmod, int J, int widx, int 
 // stage_events (optional, whole passes only): hipEvent_t per stage, recorded - on whichever stream finishes the stage's gradients - as soon as
 // the gradient tensors of that stage are final, so the caller can start reducing them without the streams being joined at every stage.
 static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
-                         int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos, void* const* stage_events) {
+                         int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos, void* const* stage_events,
+                         bool join = true) {
   RUN(check_common(p, B, params, ws, ws_bytes, true, "vit_backward"));
   RUN(check_geom(p, pmap, pos, "vit_backward"));
   V4H_CHECK_ARG(grads != nullptr, "vit_backward: null gradient table");
@@ -844,7 +845,8 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   const Mode m = p->mode;
   const int BT = c.BT(), D = p->D, M = p->M, T = p->T, depth = p->depth;
   RUN(side_init(*p));
-  p->mark_live = 0;
+  // (the side-stream marks of a pass issued as several calls WITHOUT a join in between - v4h_vit_backward_stage - stay live from call to call)
+  if (stage_first == 0) p->mark_live = 0;
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
   auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
   // A backward pass issued as ONE call handles every adaLN Linear of the step together at the end (one cast, one grouped weight-gradient
@@ -854,7 +856,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   const int ldm = p->ldmod();
   const bool whole_pass = stage_first == 0 && stage_last == depth + 1;
   auto stage_done = [&](int st, hipStream_t on) -> int {
-    if (stage_events && hipEventRecord((hipEvent_t)stage_events[st], on) != hipSuccess) { v4h_set_error("vit_backward: cannot record the event of stage %d", st); return V4H_ERR_HIP; }
+    if (stage_events && stage_events[st] && hipEventRecord((hipEvent_t)stage_events[st], on) != hipSuccess) { v4h_set_error("vit_backward: cannot record the event of stage %d", st); return V4H_ERR_HIP; }
     return V4H_OK;
   };
   // (with stage events the caller reduces each block's gradients while the pass runs: every block's adaLN gradients must be final with its stage)
@@ -1064,7 +1066,7 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   }
   // Join: every gradient of the stages of this call is complete (in stream order) when the call returns, and no weight-gradient
   // kernel is left reading a temporary the next call may overwrite.
-  if (g_overlap_wgrad) RUN(main_wait_side(*p, c.s));
+  if (g_overlap_wgrad && (join || stage_last == depth + 1)) RUN(main_wait_side(*p, c.s));
   if (stage_last == depth + 1) RUN(stage_done(depth + 1, c.s));
   return V4H_OK;
 }
@@ -1072,6 +1074,20 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
 extern "C" int32_t v4h_vit_backward(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
                                     int32_t stage_first, int32_t stage_last, void* stream, const int32_t* pmap, const float* pos) {
   return backward_impl(p, B, params, grads, dout, ws, ws_bytes, stage_first, stage_last, stream, pmap, pos, nullptr);
+}
+// One stage of a pass that is issued stage by stage WITHOUT joining the library's two streams after every stage (the drop-in DDP route, round 5):
+// `stage_event` (optional) is recorded - on whichever stream finishes them - when the gradients of THIS stage are final; the caller makes its stream wait for
+// that event before it hands the stage's gradients on (one stage later, when the event has long been reached), instead of stalling the main stream for the
+// weight-gradient stream's tail at every stage.  The last stage (embedders) always ends with the full join.  Stages must be issued in order 0 ... depth + 1.
+extern "C" int32_t v4h_vit_backward_stage(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws, size_t ws_bytes,
+                                          int32_t stage, void* stream, const int32_t* pmap, const float* pos, void* stage_event, int32_t join) {
+  V4H_CHECK_ARG(p != nullptr && stage >= 0 && stage < p->depth + 2, "vit_backward_stage: null plan or bad stage %d", stage);
+  std::vector<void*> evs;
+  if (stage_event) {
+    evs.assign(p->depth + 2, nullptr);
+    evs[stage] = stage_event;
+  }
+  return backward_impl(p, B, params, grads, dout, ws, ws_bytes, stage, stage, stream, pmap, pos, stage_event ? evs.data() : nullptr, join != 0);
 }
 extern "C" int32_t v4h_vit_backward_events(const v4h_plan* p, int32_t B, const void* const* params, void* const* grads, const float* dout, void* ws,
                                            size_t ws_bytes, void* stream, const int32_t* pmap, const float* pos, void* const* stage_events) {
