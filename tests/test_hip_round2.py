@@ -172,8 +172,12 @@ def test_ddp_wrapped_net_matches_single_process_gradients():
         finally:
             dist.destroy_process_group()
         assert abs(l1 - l0).item() / l0.item() < 1e-6
-        for k in g0:  # ... and hold DDP to twice the spread the plain path shows on that tensor (floors: f32 1e-5, bf16 2e-3 = the deterministic part)
-            assert U.rel_err(g1[k], g0[k]) <= max(1e-5 if mode == "f32" else 2e-3, 2.0 * spread[k]), (mode, k, spread[k])
+        # ... and hold DDP to twice the spread the plain path shows on that tensor (floors: f32 1e-5; bf16 5e-3 = one bf16 ulp of the tensor's largest
+        # element plus slack: under a process group the adaLN gradients are summed per block instead of in one grouped contraction - other f32 atomic
+        # orders in d silu(cond), whose bf16 operand copy can then differ by one ulp in an element; seen as 4.4e-3 on c_embedder.0.weight in one of three
+        # runs of round 5, with and without the shifted hand-over of the staged nodes)
+        for k in g0:
+            assert U.rel_err(g1[k], g0[k]) <= max(1e-5 if mode == "f32" else 5e-3, 2.0 * spread[k]), (mode, k, spread[k])
 
 
 # ---------------------------------------------------------------------------------------------------------------- non-finite gradients

@@ -1167,13 +1167,9 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   V4H_CHECK_ARG(!r16 || (al && combo >= 0 && ln_resid16_supported(m, a.D)),
                 "ln_modulate_bwd: 16-bit residual storage needs bf16 mode, hidden_dim %d a multiple of 8 up to 512, aligned tensors and one of the backward pass's option sets", a.D);
   if ((v2 > 0 || r16) && al && a.D % 8 == 0 && a.D <= 512 && combo >= 0) {
-    static const int lnb_rows = getenv("V4H_LNB_ROWS") ? atoi(getenv("V4H_LNB_ROWS")) : 8;  // rows per workgroup (A/B hook): 8, 16 or 24
-#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_)                                                                                                                  \
-  do {                                                                                                                                                       \
-    if (lnb_rows == 16) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 16, 4, 1, A, B_, C_, D_>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a); \
-    else if (lnb_rows == 24) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 24, 4, 1, A, B_, C_, D_>), dim3((a.T + 23) / 24, a.B), dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 8, 4, 1, A, B_, C_, D_>), dim3((a.T + 7) / 8, a.B), dim3(256), 0, s, a);            \
-  } while (0)
+    // (8 rows per workgroup of 4 waves; 16 and 24 rows - fewer per-sample float atomics - re-measured with the bf16 streams of round 5: 256.5 / 255.3 vs
+    //  256.0 steps/s, neutral)
+#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 8, 4, 1, A, B_, C_, D_>), dim3((a.T + 7) / 8, a.B), dim3(256), 0, s, a)
 #define V4H_LNB2_COMBO(TT, XT, GT)                                     \
   do {                                                                 \
     if (combo == 0) V4H_LNB2(TT, XT, GT, false, true, true, false);    \
