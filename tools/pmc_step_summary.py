@@ -82,13 +82,15 @@ def exact_fetch(k):
     return 32 * n32 + 64 * n64 + 128 * n128 + 64 * other
 
 
-# Algorithmic HBM bytes per call of the ds2 bs = 128 update step (BT = 17280 tokens, D = 480, M = 1920, bf16 activations, f32 residual stream): every
+# Algorithmic HBM bytes per call of the ds2 bs = 128 update step (BT = 17280 tokens, D = 480, M = 1920, bf16 activations, bf16 residual streams - round 5): every
 # operand read once, every result written once, with the activation-materialising structure of the path (each Linear writes its output).
 BT, D, M = 17280, 480, 1920
 ALGO = {  # short kernel name -> (read MB per call, written MB per call, what)
-    "ln_modulate_fwd8_kernel": ((BT * D * 6) / 1e6, (BT * D * 6) / 1e6, "x f32 + y bf16 -> x' f32 + u bf16"),
+    "ln_modulate_fwd8_kernel": ((BT * D * 4) / 1e6, (BT * D * 4) / 1e6, "x bf16 + y bf16 -> x' bf16 + u bf16"),
     "ln_modulate_bwd8_kernel": ((BT * D * 12) / 1e6, (BT * D * 6) / 1e6, "du bf16 + x f32 + dx f32 + y bf16 -> dx f32 + dy bf16"),
-    "ln_modulate_bwd8v2_kernel": ((BT * D * 12) / 1e6, (BT * D * 6) / 1e6, "du bf16 + x f32 + dx f32 + y bf16 -> dx f32 + dy bf16 (round-4 form)"),
+    "ln_modulate_bwd8v2_kernel": ((BT * D * 8) / 1e6, (BT * D * 4) / 1e6, "du bf16 + x bf16 + dx bf16 + y bf16 -> dx bf16 + dy bf16"),
+    "v4h_gemm3_kernel<Gemm3Cfg<false, 0, 3": ((BT * D * 2 + 3 * D * D * 2) / 1e6, (BT * 3 * D * 2) / 1e6, "qkv forward, weight-stationary: u1 + W -> qkv"),
+    "v4h_gemm3_kernel<Gemm3Cfg<false, 0, 2": ((BT * D * 2 + D * D * 2) / 1e6, (BT * D * 2) / 1e6, "attn.proj forward, weight-stationary: o + W -> y1"),
     "adamw_sched_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),
     "gemm<bf16,fwd,128x128x64,GELU>": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "u2 + W -> h + gelu' (128 x 128 tiles)"),
     "gemm<bf16,dgrad,128x128x64,DGELU>": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "dy + W + gelu' -> dh (128 x 128 tiles)"),
@@ -97,7 +99,7 @@ ALGO = {  # short kernel name -> (read MB per call, written MB per call, what)
     "adamw_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),
     "gemm<bf16,fwd,128x160x64,GELU>": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "u2 + W -> h + gelu'"),
     "gemm<bf16,dgrad,128x160x64,DGELU>": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "dy + W + gelu' -> dh"),
-    "gemm2<bf16,fwd,256x160x64,STORE,ping-pong>": ((BT * (D + D + M) * 2 + (3 * D * D + D * D + D * M) * 2) / 3e6, (BT * (3 * D + D + D) * 2) / 3e6, "mean of qkv, proj, fc2"),
+    "gemm2<bf16,fwd,256x160x64,STORE,ping-pong>": ((BT * M * 2 + D * M * 2) / 1e6, (BT * D * 2) / 1e6, "fc2 forward: h + W -> y2"),
     "gemm2<bf16,dgrad,256x160x64,STORE,ping-pong>": ((BT * (3 * D + D + M) * 2 + (3 * D * D + D * D + D * M) * 2) / 3e6, (BT * 3 * D * 2) / 3e6, "mean of d qkv, d proj, d fc1"),
     "gemm2<bf16,wgrad,256x160x64,SLAB_F32,colsum,ping-pong>": ((BT * ((3 * D + D) + (M + D) + (D + M)) * 2) / 3e6, (8 * (3 * D * D + 2 * D * M) * 4) / 3e6, "mean of qkv, fc1, fc2: dY + X -> 8 f32 slabs"),
 }
