@@ -201,13 +201,20 @@ class _ViTFunction(torch.autograd.Function):
         params = [p.detach() for p in ctx.saved_tensors]
         g = _lib.require_cuda(grad_out, "grad_output")
         dout = _unpatchify(net, g) if ctx.patches_io else g
-        sizes = [(p.numel() + 63) // 64 * 64 for p in params]  # 256-byte aligned slices of one zeroed buffer
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dout.device)
+        sizes = [(p.numel() + 63) // 64 * 64 for p in params]  # 256-byte aligned slices of one buffer
+        # the node owns this buffer: the pass WRITES every gradient (gradient mode 1 around this call only; the plan is shared with accumulating callers),
+        # so no 104 MB zero fill per backward
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dout.device)
         grads, off = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[off : off + p.numel()].view_as(p))
             off += n
-        run_backward(net, params, grads, dout, ctx.ws)
+        plan_h = net._get_plan().handle
+        _lib.check(_lib.load().v4h_plan_set_gradient_mode(plan_h, 1), "v4h_plan_set_gradient_mode")
+        try:
+            run_backward(net, params, grads, dout, ctx.ws)
+        finally:
+            _lib.load().v4h_plan_set_gradient_mode(plan_h, 0)
         ctx.ws = None
         return (None, None, None, None, None, *grads)
 
@@ -259,21 +266,28 @@ def _run_stage(ps, stage):
         STAGE_LOG.append(("stage", stage))
     if ps.tables is None:
         ps.tables = (_lib.pointer_table(ps.params), _lib.pointer_table(ps.grads))
-    if not ps.late:
-        run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage, tables=ps.tables)
-        return
     plan = ps.net._get_plan()
-    dev = ps.ws.device
-    if ps.events is None:
-        ps.events = _stage_events(ps.net, plan.num_stages, dev)
-    pmap, pos = ps.net.device_tables(dev)
-    last = stage == plan.num_stages - 1
-    with _lib.on_device(ps.ws):
-        _lib.check(
-            _lib.load().v4h_vit_backward_stage(plan.handle, ps.dout.shape[0], ps.tables[0], ps.tables[1], _lib.ptr(ps.dout), _lib.ptr(ps.ws), ps.ws.numel(), stage,
-                                               _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos), None if last else ps.events[stage].cuda_event, 1 if last else 0),
-            "v4h_vit_backward_stage",
-        )
+    lib = _lib.load()
+    # The pass owns its private gradient buffer: every stage WRITES its gradients (gradient mode 1, set around this call only - the plan is shared with
+    # accumulating callers), so the buffer is allocated without the 104 MB zero fill.
+    _lib.check(lib.v4h_plan_set_gradient_mode(plan.handle, 1), "v4h_plan_set_gradient_mode")
+    try:
+        if not ps.late:
+            run_backward(ps.net, ps.params, ps.grads, ps.dout, ps.ws, stage, stage, tables=ps.tables)
+            return
+        dev = ps.ws.device
+        if ps.events is None:
+            ps.events = _stage_events(ps.net, plan.num_stages, dev)
+        pmap, pos = ps.net.device_tables(dev)
+        last = stage == plan.num_stages - 1
+        with _lib.on_device(ps.ws):
+            _lib.check(
+                lib.v4h_vit_backward_stage(plan.handle, ps.dout.shape[0], ps.tables[0], ps.tables[1], _lib.ptr(ps.dout), _lib.ptr(ps.ws), ps.ws.numel(), stage,
+                                           _lib.stream_ptr(dev), _lib.ptr(pmap), _lib.ptr(pos), None if last else ps.events[stage].cuda_event, 1 if last else 0),
+                "v4h_vit_backward_stage",
+            )
+    finally:
+        lib.v4h_plan_set_gradient_mode(plan.handle, 0)
 
 
 def _await_stage(ps, stage):
@@ -328,13 +342,13 @@ class _StageFinal(torch.autograd.Function):
         ps = ctx.ps
         g = _lib.require_cuda(grad_out, "grad_output")
         ps.dout = _unpatchify(ps.net, g) if ps.patches_io else g
-        sizes = [(p.numel() + 63) // 64 * 64 for p in ps.params]  # 256-byte aligned slices of one zeroed buffer
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=ps.dout.device)
+        sizes = [(p.numel() + 63) // 64 * 64 for p in ps.params]  # 256-byte aligned slices of one buffer (written, not accumulated into: _run_stage)
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=ps.dout.device)
         ps.grads, off = [], 0
         for p, n in zip(ps.params, sizes):
             ps.grads.append(flat[off : off + p.numel()].view_as(p))
             off += n
-        ps.carrier_grad = flat[:1]  # any defined tensor: the carriers carry no data
+        ps.carrier_grad = torch.zeros(1, dtype=torch.float32, device=ps.dout.device)  # any defined tensor: the carriers carry no data
         _run_stage(ps, 0)
         return (None, ps.carrier_grad, None, *[ps.grads[k] for k in ctx.idx])
 
