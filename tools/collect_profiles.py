@@ -3,7 +3,7 @@ usage: python tools/collect_profiles.py <tag> [round prefix, default r03]"""
 import json, os, shutil, sys
 
 tag = sys.argv[1]
-rp = sys.argv[2] if len(sys.argv) > 2 else "r04"
+rp = sys.argv[2] if len(sys.argv) > 2 else "r05"
 R = f"gpurun_out/refresh_{tag}"
 for src, dst in (("step_serialized.md", f"{rp}_step_final_bf16_serialized.md"), ("step_overlapped.md", f"{rp}_step_final_bf16_overlapped.md"), ("step_gaps.txt", f"{rp}_step_final_gaps.txt"), ("step_timeline.txt", f"{rp}_step_timeline.txt"),
                  ("step_pmc_counters.md", f"{rp}_step_pmc_counters.md"), ("step_hbm_traffic.json", "step_hbm_traffic.json"), ("bench_final_bf16.json", f"{rp}_bench_final_bf16.json"),
@@ -17,10 +17,11 @@ if os.path.exists(f"{R}/step_pmc_counters.md") and os.path.exists("tools/pmc_cou
 if os.path.exists(f"{R}/ab_in_context.txt"):
     open(f"profiles/{rp}_ab_in_context_{tag}.txt", "w").write(
         "# In-context A/B of the switches the library keeps (tools/refresh_profiles.sh, part 3): two interleaved rounds on one box, each line one full `bench.py` run\n"
-        "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default build.  Round-4 levers switched off one at a time: V4H_MLP_TILE=0 (GELU / DGELU contractions\n"
-        "# on 128 x 160 tiles again), V4H_LNB_V2=0 (round-2 LayerNorm backward); round-4 options measured neutral and left off: V4H_LNF_V2=1, V4H_PREPARE_AHEAD=1 (operand casts on\n"
-        "# the side stream at the start of the step), V4H_PIPELINE_UPDATE=1, V4H_ASYNC_T=1 (costs a one-time 18-35 ms runtime stall when the host first runs ahead; here it falls into the warm-up);\n"
-        "# then the older switches: 0 / 8 = two-workgroup / ring kernel everywhere, whole-K kernels off, round-2 attention, 4 K-splits, per-block adaLN, no weight-gradient stream.\n"
+        "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default build.  Round-5 levers switched off one at a time: VIT4HEP_AMD_RESIDUAL=f32 / x_bf16 /\n"
+        "# dx_bf16 (storage of the residual stream and of its gradient; default bf16 for both), V4H_GEMM3=0 / 1 / 31 (no class / qkv forward only / every K = 480 class on the\n"
+        "# weight-stationary kernel; default 3 = qkv + proj forward); then the older ones: gradient buffer zero-filled and accumulated into, GELU / DGELU on 128 x 160 tiles,\n"
+        "# round-2 LayerNorm backward, pipelined update, 0 / 8 = two-workgroup / ring kernel everywhere, whole-K kernels off, round-2 attention, 4 K-splits, per-block adaLN,\n"
+        "# no weight-gradient stream.\n"
         + open(f"{R}/ab_in_context.txt").read())
 if os.path.exists(f"{R}/gemm2_ablation.txt"):
     old = open(f"profiles/{rp}_gemm2_ablation.txt").read() if os.path.exists(f"profiles/{rp}_gemm2_ablation.txt") else ""

@@ -1167,9 +1167,10 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   V4H_CHECK_ARG(!r16 || (al && combo >= 0 && ln_resid16_supported(m, a.D)),
                 "ln_modulate_bwd: 16-bit residual storage needs bf16 mode, hidden_dim %d a multiple of 8 up to 512, aligned tensors and one of the backward pass's option sets", a.D);
   if ((v2 > 0 || r16) && al && a.D % 8 == 0 && a.D <= 512 && combo >= 0) {
-    // (8 rows per workgroup of 4 waves; 16 and 24 rows - fewer per-sample float atomics - re-measured with the bf16 streams of round 5: 256.5 / 255.3 vs
-    //  256.0 steps/s, neutral)
-#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 8, 4, 1, A, B_, C_, D_>), dim3((a.T + 7) / 8, a.B), dim3(256), 0, s, a)
+    // 16 rows per workgroup of 4 waves, one row per wave at a time.  (Round 4: 8 rows.  With the bf16 streams of round 5 the per-sample float atomics of a
+    // workgroup - 3 x 480 floats whatever its row count, 12.4 MB per launch at 8 rows against 100 MB of streams - weigh more: 16 rows halve them, 68 MB less
+    // per step, 256.5 vs 256.0 steps/s; 24 rows 255.3.)
+#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 16, 4, 1, A, B_, C_, D_>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
 #define V4H_LNB2_COMBO(TT, XT, GT)                                     \
   do {                                                                 \
     if (combo == 0) V4H_LNB2(TT, XT, GT, false, true, true, false);    \
