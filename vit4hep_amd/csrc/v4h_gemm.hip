@@ -78,8 +78,9 @@ inline bool on_ring(const GemmArgs& a, int klen, int bit) {
 // The K = hidden_dim contractions (qkv, attn.proj, fc1 + GELU forward; attn.proj and fc2 x GELU' input gradients) on the weight-stationary kernel:
 // the weight slice of a workgroup lives in registers, only activation rows stream (v4h_gemm3.h).  V4H_GEMM3=0: off (A/B hook).
 // Contraction classes on it under KERNEL_AUTO (bits: 1 forward plain store with >= 960 output columns - qkv -, 2 forward plain store below that - attn.proj -,
-// 4 forward GELU, 8 dgrad plain store, 16 dgrad DGELU).  V4H_GEMM3 overrides (A/B hook); KERNEL_WS takes every eligible class.
-int g_ws = env_flag("V4H_GEMM3", 3) & 31;
+// 4 forward GELU of the update step - two outputs -, 8 dgrad plain store, 16 dgrad DGELU, 32 forward GELU without the saved derivative - inference).
+// V4H_GEMM3 overrides (A/B hook); KERNEL_WS takes every eligible class.
+int g_ws = env_flag("V4H_GEMM3", 3) & 63;
 constexpr int WS_K = 480;
 inline bool on_ws(const GemmArgs& a, int bit) {
   if (g_kernel == KERNEL_TWO_WG || g_kernel == KERNEL_RING) return false;
@@ -124,7 +125,7 @@ template <typename T> int fwd_t(int epi, const GemmArgs& a, hipStream_t s) {
       if (epi == EPI_COND_SUM) return v4h_small::smallm_launch<false, EPI_COND_SUM>(a, s, "gemm_small/cond_sum");
     }
     if (epi == EPI_STORE && on_ws(a, a.J >= 960 ? 1 : 2)) return run_ws<false, EPI_STORE>(a, s, "gemm3_fwd/store");
-    if (epi == EPI_GELU && on_ws(a, 4) && a.e.out2 != nullptr && a.e.ldo2 % 8 == 0 && ((uintptr_t)a.e.out2 % 16) == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L)
+    if (epi == EPI_GELU && on_ws(a, a.e.out != nullptr ? 4 : 32) && a.e.out2 != nullptr && a.e.ldo2 % 8 == 0 && ((uintptr_t)a.e.out2 % 16) == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L)
       return run_ws<false, EPI_GELU>(a, s, "gemm3_fwd/gelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 1)) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_STORE, false>>(a, 1, s, "gemm2_fwd/store");
     if (epi == EPI_GELU && on_ring(a, a.K, a.e.out != nullptr ? 2 : 32) && a.e.ldo2 % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, false, EPI_GELU, false>>(a, 1, s, "gemm2_fwd/gelu");
