@@ -2,12 +2,13 @@
 # Re-measure everything profiles/ quotes for the update step, on the GPU box:  bash tools/refresh_profiles.sh <tag> [part ...]
 #   part 1: PMC passes + traffic json, the full bench line, overlapped / serialized kernel profiles, gaps     (~8 min)
 #   part 2: the other workloads, f32, forced collectives, ds3 serialized profile, ablation build               (~6 min)
-#   part 3: in-context A/B of the kept switches, block contraction bench, attention bench, comm rehearsal      (~8 min)
+#   part 3: in-context A/B of the kept switches                                                                (~10 min)
+#   part 4: block contraction bench, attention bench, comm rehearsal, DDP route rehearsal                      (~8 min)
 # Writes gpurun_out/refresh_<tag>/...; copy what should be judged into profiles/ (python tools/collect_profiles.py <tag> does).
 set -e -o pipefail
 tag=${1:-r05}
 shift || true
-parts="${*:-1 2 3}"
+parts="${*:-1 2 3 4}"
 out=gpurun_out/refresh_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -56,7 +57,9 @@ for r in 1 2; do
   done
 done
 echo "A/B done"
-python3 tools/block_gemm_bench.py 17280 5 > $out/block_gemm_bench.txt 2>&1 || echo "block bench failed"
+fi
+if has 4; then
+KERNELS=1,2,3 python3 tools/block_gemm_bench.py 17280 5 > $out/block_gemm_bench.txt 2>&1 || echo "block bench failed"
 python3 tools/attn_bench.py > $out/attn_bench.txt 2>&1 || echo "attn bench failed"
 python3 tools/comm_interference.py --steps 30 --rounds 2 > $out/comm_interference.txt 2> $out/comm_interference.err || echo "comm rehearsal failed"
 python3 tools/ddp_route_bench.py --steps 20 --rounds 2 > $out/ddp_route.txt 2> $out/ddp_route.err || echo "DDP route rehearsal failed"
