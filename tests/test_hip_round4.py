@@ -150,11 +150,15 @@ def _grads(model, x, c, t, x0):
 _DETERMINISTIC = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")  # split-K slabs + ordered reduce: no float atomics
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
-def test_staged_autograd_nodes_match_the_single_node(mode, monkeypatch):
+@pytest.mark.parametrize("mode,late", [("f32", "1"), ("bf16", "1"), ("f32", "0")])
+def test_staged_autograd_nodes_match_the_single_node(mode, late, monkeypatch):
     """The chain of per-stage nodes (one forward call, backward stage by stage) gives the gradients of the one-node form: the block weight gradients
-    bit for bit (deterministic kernels), the rest within the run-to-run spread of the atomically summed tensors."""
+    bit for bit (deterministic kernels), the rest within the run-to-run spread of the atomically summed tensors.  late = 1 (round 5, the default with every
+    parameter trainable): no join of the library's streams per stage, a node hands on the gradients of the stage before it behind that stage's event
+    (v4h_vit_backward_stage); late = 0: the round-4 form, every stage joins and returns its own gradients."""
     import vit4hep_amd.autograd as AG
+
+    monkeypatch.setenv("V4H_STAGED_LATE", late)
 
     cfg = O.ds2(3)
     fill = O.golden_fill(cfg)

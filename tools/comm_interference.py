@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--lds", type=int, default=16384)
     ap.add_argument("--ranks", type=int, default=8, help="ranks of the rehearsed job: a ring all-reduce moves 2 (ranks-1)/ranks of every bucket")
+    ap.add_argument("--grad-allreduce", default=None, choices=[None, "bf16"], help="bf16: CFMTrainer(grad_allreduce='bf16') - the stand-in then moves half the bytes, the casts run for real")
     ap.add_argument("--only", default="", help="comma-free substring filter on variant names, ';'-separated (e.g. 'single;nwg=16,reserve=0,gbps=300')")
     args = ap.parse_args()
     assert torch.cuda.is_available()
@@ -72,7 +73,7 @@ def main():
     sl = standin_lib()
     w = bench.WORKLOADS["ds2"]
     model = bench.build_model(w, "bf16", "cuda:0")
-    trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000)
+    trainer = CFMTrainer(model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad_norm=1000.0, iterations=50000, grad_allreduce=args.grad_allreduce)
     x, c = bench.synthetic(w["shape"], w["B"], seed=0, device="cuda:0", cond=w["cond"])
     torch.manual_seed(1000)
     factor = 2.0 * (args.ranks - 1) / args.ranks
