@@ -19,6 +19,12 @@
 //     just finished, DMA of the tile five ahead) in opposite order between two barriers, so a SIMD's matrix pipe nearly always has a wave with MFMAs to issue;
 //   * A image [octet of chunks][16 rows][8 chunks, XOR-swizzled as in v4h_gemm.h]: a DMA piece is 8 rows x 128 contiguous bytes with the lanes of a quad on
 //     consecutive chunks of one row, and the 16 lanes of every ds_read_b128 service group fall on 16 different 16-byte bank groups (tools/lds_model.py).
+//
+// Where it stands (round 5, profiles/r05_notes.md section 2 with the slot timelines): the streaming part runs at 82 % of the matrix pipe and takes half the ring
+// kernel's time per row, but no MFMA can start before the 368 KB (245 KB) of a workgroup's weight slice are in its registers - 9-10 us at the 23-26 bytes / clock
+// a CU gets out of the L2s when all 256 pull the same 1.4 MB (direct fragment loads and whole-line DMA through the LDS alike).  Default classes: qkv and
+// attn.proj forward (qkv 33-35 us instead of 47-48 cold; +0.7 % on the update step, +2-3 % on the sampler); the GELU / DGELU forms (vector-issue-bound
+// epilogues in series with the matrix slot of the same wave) and the plain dgrad form stay on the other kernels (csrc/v4h_gemm.hip: g_ws).
 #pragma once
 #include "v4h_gemm2.h"
 
@@ -50,15 +56,8 @@ template <int KS, int S> V4H_DEV void g3_read(Frag<bf16>& f, unsigned a0, unsign
 }
 template <int KS, int NT, int S> struct G3Step {
   static V4H_DEV void run(f32x4 (&acc)[NT], const Frag<bf16> (&bq)[KS][NT], Frag<bf16> (&p)[3], unsigned a0, unsigned a0h, unsigned a1) {
-#if defined(V4H_G3_EXP) && V4H_G3_EXP == 1   // timing experiment (wrong results): no fragment reads behind the first two
-    constexpr int younger = S == 0 ? 1 : 0;
-#elif defined(V4H_G3_EXP) && V4H_G3_EXP == 2  // timing experiment: one slab ahead only
-    if constexpr (S + 2 < KS && S % 1 == 0) g3_read<KS, S + 2>(p[(S + 2) % 3], a0, a0h, a1);
-    constexpr int younger = 0 * S;
-#else
     if constexpr (S + 2 < KS) g3_read<KS, S + 2>(p[(S + 2) % 3], a0, a0h, a1);
     constexpr int younger = (KS - 1 - S) < 2 ? (KS - 1 - S) : 2;  // reads issued behind the one this step needs
-#endif
     if constexpr (S == 0) {  // the bias reads (into the accumulators) are older still: the same wait covers them
       if constexpr (NT == 3) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p[0].v), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "n"(younger));
       else asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(p[0].v), "+v"(acc[0]), "+v"(acc[1]) : "n"(younger));
@@ -73,7 +72,7 @@ template <int KS, int NT, int S> struct G3Step {
 };
 
 #ifdef V4H_GEMM3_STAMPS
-// Diagnostic build only (V4H_EXTRA_FLAGS="-DV4H_ABLATIONS -DV4H_GEMM3_STAMPS"): every wave stamps the shader clock at the boundaries of its slots - into 4 KB of
+// Diagnostic build only (V4H_BUILD_TAG=st3 V4H_EXTRA_FLAGS=-DV4H_GEMM3_STAMPS): every wave stamps the shader clock at the boundaries of its slots - into 4 KB of
 // LDS behind the ring (no vector-memory instruction, the counted waits are untouched) - and copies them out at the end (tools/experiments/gemm3_stamps.py).
 constexpr int G3_ST_N = 128;
 __device__ unsigned v4h_gemm3_stamp_buf[256 * 8 * G3_ST_N];
@@ -343,12 +342,6 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
     // Interval t (between two barriers): every wave computes tile t from ring slot `slot`, requests its share of tile t + R - 1 into the slot tile t - 1
     // left at the last barrier, and writes one finished tile: half 0 the one it has just computed (matrix slot first), half 1 the previous one (auxiliary
     // slot first, its accumulators survive the barrier) - the two waves of a SIMD run the two slots in opposite order.
-#if defined(V4H_G3_EXP) && V4H_G3_EXP == 3   // timing experiment (wrong results): matrix slots only
-    if (active) matrix(slot);
-    V4H_G3_STAMP();
-    mk[C::R - 2] = ops;
-    if (t_end == 12345678) { ops += epi_pre(t); ops += issue(); ops += epi_post(t); }
-#else
     if (half == 0) {
       if (active) matrix(slot);
       V4H_G3_STAMP();  // 5 + 4 i: first slot done
@@ -364,7 +357,6 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       V4H_G3_STAMP();
       if (active) matrix(slot);
     }
-#endif
     V4H_G3_STAMP();  // 6 + 4 i: second slot done
     // before the barrier: this wave's share of tile t + 1 has landed (everything it issued afterwards may stay in flight)
     wait_counted(sgpr(ops - mk[0]));
