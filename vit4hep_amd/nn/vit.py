@@ -167,9 +167,9 @@ class ViT(nn.Module):
             raise NotImplementedError("vit4hep_amd: dropout > 0 is not on the shape-CFM path")
         if self.checkpoint_grads:
             # nn/vit.py:201-202 wraps every block in torch.utils.checkpoint: a memory / recompute trade-off with no numerical effect.  The library keeps
-            # every activation (the whole training workspace is 2.3 GB of 288 GB at ds2 bs 128) and has no recompute path: say so instead of ignoring it.
+            # every activation (the whole training workspace is 2.4 GB of 288 GB at ds2 bs 128) and has no recompute path: say so instead of ignoring it.
             raise NotImplementedError("vit4hep_amd: checkpoint_grads=True (block recompute) is not built - the HIP path keeps all activations "
-                                      "(2.3 GB at ds2 bs 128); set checkpoint_grads: false, the results are identical")
+                                      "(2.4 GB at ds2 bs 128); set checkpoint_grads: false, the results are identical")
         self.num_patches = [list(int(v) for v in seg) for seg in self.num_patches]
         if self.dim != 3 or len(self.num_patches) < 1 or any(len(seg) != 3 for seg in self.num_patches):
             raise NotImplementedError("vit4hep_amd: num_patches must be a list of 3-D patch segments [[l, a, r], ...]")
