@@ -82,6 +82,50 @@ struct GemmArgs {
 
 // 8-wide vector helpers (one lane owns 8 consecutive output columns of a row)
 struct f32x8 { float v[8]; };
+// The same two functions on the 8 consecutive columns a lane owns in an epilogue.  bf16 mode: written on PAIRS of elements (ext_vector_type(2) floats =
+// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, two elements per issue slot); only the exponential and the reciprocal stay one instruction per element.
+// Per element and issue slot: 5 packed + 2 transcendental instead of 12 + 2 (training form), 3 + 2 instead of 6 + 2 (inference form) - the
+// compiler packs the scalar form only in part.  log2(e) is folded into the polynomial's constants: s = 1 / (1 + 2^(x (a' + b' x^2))).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> V4H_DEV void gelu8_and_grad(f32x8& v, f32x8& d) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+}
+template <typename T> V4H_DEV void gelu8_only(f32x8& v) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v.v[r] = gelu_only<T>(v.v[r]);
+}
+V4H_DEV f32x2 gelu_sigmoid2(f32x2 x, f32x2 x2) {
+  const f32x2 w = x * (x2 * (-1.4426950409f * 0.0713548163f) + (-1.4426950409f * 1.5957691216f));
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(w.x);
+  e.y = __builtin_amdgcn_exp2f(w.y);
+  e = e + 1.0f;
+  f32x2 s;
+  s.x = __builtin_amdgcn_rcpf(e.x);
+  s.y = __builtin_amdgcn_rcpf(e.y);
+  return s;
+}
+template <> V4H_DEV void gelu8_and_grad<bf16>(f32x8& v, f32x8& d) {
+#pragma unroll
+  for (int r = 0; r < 8; r += 2) {
+    const f32x2 x = {v.v[r], v.v[r + 1]};
+    const f32x2 x2 = x * x;
+    const f32x2 s = gelu_sigmoid2(x, x2);
+    const f32x2 y = x * s;
+    const f32x2 dy = (y * (1.0f - s)) * (x2 * 0.2140644489f + 1.5957691216f) + s;
+    v.v[r] = y.x; v.v[r + 1] = y.y;
+    d.v[r] = dy.x; d.v[r + 1] = dy.y;
+  }
+}
+template <> V4H_DEV void gelu8_only<bf16>(f32x8& v) {
+#pragma unroll
+  for (int r = 0; r < 8; r += 2) {
+    const f32x2 x = {v.v[r], v.v[r + 1]};
+    const f32x2 y = x * gelu_sigmoid2(x, x * x);
+    v.v[r] = y.x; v.v[r + 1] = y.y;
+  }
+}
 V4H_DEV float& at(f32x8& x, int r) { return x.v[r]; }
 V4H_DEV f32x8 make8(f32x4 lo, f32x4 hi) {
   f32x8 x;
@@ -223,12 +267,10 @@ template <int EPI, typename T, typename TO> struct Epilogue {
     } else if constexpr (EPI == EPI_GELU) {
       if (e.out) {  // training: the derivative is kept for the backward
         f32x8 d;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+        gelu8_and_grad<T>(v, d);
         store8_saved(reinterpret_cast<TO*>(e.out) + (size_t)i * e.ldo + j, d);
       } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v.v[r] = gelu_only<T>(v.v[r]);
+        gelu8_only<T>(v);
       }
       store8(reinterpret_cast<TO*>(e.out2) + (size_t)i * e.ldo2 + j, v);
     } else if constexpr (EPI == EPI_DGELU) {
@@ -767,12 +809,10 @@ template <class C> __global__ __launch_bounds__(C::NT, (C::NT == 256 ? 2 : 1)) v
         } else {  // EPI_GELU: out = gelu'(pre) (training only), out2 = gelu(pre)
           if (a.e.out) {
             f32x8 d;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) gelu_and_grad<T>(v.v[r], v.v[r], d.v[r]);
+            gelu8_and_grad<T>(v, d);
             if (ok) store8_saved(reinterpret_cast<TO*>(a.e.out) + (size_t)i * a.e.ldo + j, d);
           } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v.v[r] = gelu_only<T>(v.v[r]);
+            gelu8_only<T>(v);
           }
           if (ok) store8(reinterpret_cast<TO*>(a.e.out2) + (size_t)i * a.e.ldo2 + j, v);
         }

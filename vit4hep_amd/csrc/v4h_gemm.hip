@@ -79,23 +79,29 @@ inline bool on_ring(const GemmArgs& a, int klen, int bit) {
 // the weight slice of a workgroup lives in registers, only activation rows stream (v4h_gemm3.h).  V4H_GEMM3=0: off (A/B hook).
 // Contraction classes on it under KERNEL_AUTO (bits: 1 forward plain store with >= 960 output columns - qkv -, 2 forward plain store below that - attn.proj -,
 // 4 forward GELU of the update step - two outputs -, 8 dgrad plain store, 16 dgrad DGELU, 32 forward GELU without the saved derivative - inference).
-// V4H_GEMM3 overrides (A/B hook); KERNEL_WS takes every eligible class.
-int g_ws = env_flag("V4H_GEMM3", 3) & 63;
+// V4H_GEMM3 overrides (A/B hook); KERNEL_WS takes every eligible class.  Default: every class but the plain dgrad (attn.proj's input gradient: 257.8 / 262.0
+// against 263.8 / 265.4 steps/s with it on the ring kernel).  The GELU / DGELU classes joined once their auxiliary slots were cut down - GELU written on
+// pairs of elements (v_pk_* f32), the saved derivative of the DGELU form through the DMA ring instead of buffer loads whose wait drained it, the lane part
+// of every DMA address hoisted: 259.7 / 260.4 (qkv + proj forward only, previous build) -> 267.2 / 267.3 steps/s, sampler 1528 -> 1569 showers/s, same box.
+int g_ws = env_flag("V4H_GEMM3", 55) & 63;
 constexpr int WS_K = 480;
 inline bool on_ws(const GemmArgs& a, int bit) {
   if (g_kernel == KERNEL_TWO_WG || g_kernel == KERNEL_RING) return false;
   return ((g_ws & bit) != 0 || g_kernel == KERNEL_WS) && v4h_gemm3_eligible(a, WS_K);
 }
 // Column tiles per wave: 3 where the output width allows (fewer LDS fragment reads per MFMA, fewer column slices re-reading the activations), except for
-// the epilogues that need registers of their own - GELU (value + derivative) and DGELU (the saved derivative of the tile) - which spill at 3 x 60 weight
-// registers (11 VGPRs at 256: the DGELU form took 8500 clocks per tile) and run with 2.  V4H_GEMM3_NT pins it (A/B hook).
+// the GELU form (value + derivative: fits at 252 VGPRs with 3 tiles since the packed epilogue, but measured 255.0 against 262.0 steps/s) and the DGELU form
+// (its strips of the saved derivative fit the LDS beside the ring with 2 tiles only), which run with 2.  V4H_GEMM3_NT pins it (A/B hook).
 template <bool QKS, int EPI> int run_ws(const GemmArgs& a, hipStream_t s, const char* name) {
   static const int pin = env_flag("V4H_GEMM3_NT", 0);
   int nt = v4h_gemm3_pick_nt(a.J);
   if ((EPI == EPI_GELU || EPI == EPI_DGELU) && a.J % 32 == 0) nt = 2;
   if (pin == 2 && a.J % 32 == 0) nt = 2;
   if (pin == 3 && a.J % 48 == 0) nt = 3;
-  if (nt == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
+  if constexpr (EPI != EPI_DGELU) {  // (the DGELU form's strips of the saved derivative fit the LDS beside the ring with 2 column tiles per wave only)
+    if (nt == 3) return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 3>>(a, s, name);
+  }
+  V4H_CHECK_ARG(a.J % 32 == 0, "%s: J=%d must be a multiple of 32", name, a.J);
   return v4h_gemm3_launch<Gemm3Cfg<QKS, EPI, 2>>(a, s, name);
 }
 
@@ -166,7 +172,7 @@ template <typename T> int dgrad_t(int epi, const GemmArgs& a, int splitk, hipStr
   if constexpr (sizeof(T) == 2) {
     if (g_small && epi == EPI_DSILU && v4h_small::smallm_eligible(a)) return v4h_small::smallm_launch<true, EPI_DSILU>(a, s, "gemm_small/dsilu");
     if (epi == EPI_STORE && on_ws(a, 8)) return run_ws<true, EPI_STORE>(a, s, "gemm3_dgrad/store");
-    if (epi == EPI_DGELU && on_ws(a, 16) && a.e.aux != nullptr && a.e.ld_aux % 8 == 0 && ((uintptr_t)a.e.aux % 16) == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L)
+    if (epi == EPI_DGELU && on_ws(a, 16) && a.J % 32 == 0 && a.e.aux != nullptr && a.e.ld_aux % 8 == 0 && ((uintptr_t)a.e.aux % 16) == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L)
       return run_ws<true, EPI_DGELU>(a, s, "gemm3_dgrad/dgelu");
     if (epi == EPI_STORE && on_ring(a, a.K, 4)) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_STORE, false>>(a, 1, s, "gemm2_dgrad/store");
     if (epi == EPI_DGELU && on_ring(a, a.K, 8) && a.e.ld_aux % 8 == 0) return v4h_gemm2_launch<Gemm2Cfg<false, true, EPI_DGELU, false>>(a, 1, s, "gemm2_dgrad/dgelu");

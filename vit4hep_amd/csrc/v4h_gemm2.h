@@ -310,11 +310,11 @@ template <class C> __global__ __launch_bounds__(C::NT, 2) void v4h_gemm2_kernel(
         for (int n = 0; n < C::NCHUNK; ++n) {
           f32x8 v = chunk_val(n), d;
           if (train) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) gelu_and_grad<bf16>(v.v[r], v.v[r], d.v[r]);
+            gelu8_and_grad<bf16>(v, d);
           } else {
+            gelu8_only<bf16>(v);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { v.v[r] = gelu_only<bf16>(v.v[r]); d.v[r] = 0.f; }
+            for (int r = 0; r < 8; ++r) d.v[r] = 0.f;
           }
           __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(d), rd, chunk_off(n, oA, oB, a.e.ldo) * 2u, 0, V4H_SAVED_AUX);  // (inference: zero-sized buffer, dropped)
           __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v), ro2, chunk_off(n, pA2, pB2, a.e.ldo2) * 2u, 0, 0);

@@ -20,11 +20,12 @@
 //   * A image [octet of chunks][16 rows][8 chunks, XOR-swizzled as in v4h_gemm.h]: a DMA piece is 8 rows x 128 contiguous bytes with the lanes of a quad on
 //     consecutive chunks of one row, and the 16 lanes of every ds_read_b128 service group fall on 16 different 16-byte bank groups (tools/lds_model.py).
 //
-// Where it stands (round 5, profiles/r05_notes.md section 2 with the slot timelines): the streaming part runs at 82 % of the matrix pipe and takes half the ring
-// kernel's time per row, but no MFMA can start before the 368 KB (245 KB) of a workgroup's weight slice are in its registers - 9-10 us at the 23-26 bytes / clock
-// a CU gets out of the L2s when all 256 pull the same 1.4 MB (direct fragment loads and whole-line DMA through the LDS alike).  Default classes: qkv and
-// attn.proj forward (qkv 33-35 us instead of 47-48 cold; +0.7 % on the update step, +2-3 % on the sampler); the GELU / DGELU forms (vector-issue-bound
-// epilogues in series with the matrix slot of the same wave) and the plain dgrad form stay on the other kernels (csrc/v4h_gemm.hip: g_ws).
+// Where it stands (round 5, profiles/r05_notes.md sections 2 and 7 with the slot timelines): the streaming part runs at 82 % of the matrix pipe and takes half
+// the ring kernel's time per row, but no MFMA can start before the 368 KB (245 KB) of a workgroup's weight slice are in its registers - 9-10 us at the 23-26
+// bytes / clock a CU gets out of the L2s when all 256 pull the same 1.4 MB (direct fragment loads and whole-line DMA through the LDS alike).  Default classes:
+// every K = 480 contraction of the block except attn.proj's input gradient (csrc/v4h_gemm.hip: g_ws) - qkv 33-35 us instead of 47-48 cold; the GELU / DGELU
+// forms joined when their auxiliary slots (in series with the matrix slot of the same wave, beside the partner's MFMAs) were cut from 3400 / 2200 to
+// 2170 / 1150 clocks: +2.7 % on the update step, +2.7 % on the sampler over the qkv + proj forward classes alone.
 #pragma once
 #include "v4h_gemm2.h"
 
@@ -38,11 +39,17 @@ template <bool QKS_, int EPI_, int NT_, int KS_ = 15> struct Gemm3Cfg {
   static constexpr int NPW = (NI + NW - 1) / NW;                         // per wave, at most
   static constexpr int R = 6;                                            // ring slots (tiles)
   static constexpr int BIAS_OFF = R * TILE_BYTES;
-  static constexpr int LDS_BYTES = BIAS_OFF + BJ * 4;
+  static constexpr int EPI_ST = NT == 3 ? 2 : 1;                         // 16-byte accesses per lane, tile and tensor
+  // EPI_DGELU: the saved gelu' of a tile (16 rows x BJ columns) rides the ring too - every wave requests the 1 KiB it will multiply by with its DMA share of
+  // the tile, five tiles ahead, lane-linear into a private strip (lane l's 16 bytes are the 8 columns lane l owns after the epilogue's tile exchange), and reads
+  // it back with one ds_read_b128.  R + 1 strips: half 1 writes tile t - 1 in interval t, behind the request that reuses the strip of tile t - 2.
+  static constexpr bool AUX_DMA = EPI == EPI_DGELU;
+  static constexpr int AUX_SLOTS = R + 1, AUX_WAVE = 1024 * EPI_ST, AUX_N = AUX_DMA ? EPI_ST : 0;
+  static constexpr int AUX_OFF = BIAS_OFF + BJ * 4;
+  static constexpr int LDS_BYTES = AUX_OFF + (AUX_DMA ? AUX_SLOTS * NW * AUX_WAVE : 0);
   using ImgQ = ImgKStrided<bf16, BJ, 32, NW>;                             // dgrad prologue: one K = 32 slab of the weight slice, [32][BJ]
   static constexpr int Q_ROUND = (R * TILE_BYTES) / ImgQ::BYTES;         // slabs staged per prologue round
-  static constexpr int EPI_ST = NT == 3 ? 2 : 1;                         // 16-byte accesses per lane, tile and tensor
-  static constexpr int EPI_OPS = EPI == EPI_STORE ? EPI_ST : 2 * EPI_ST; // vector-memory instructions of one epilogue (GELU: two outputs; DGELU: loads + stores)
+  static constexpr int EPI_OPS = EPI == EPI_GELU ? 2 * EPI_ST : EPI_ST; // vector-memory instructions of one epilogue (GELU: two outputs)
   static_assert(EPI == EPI_STORE || EPI == EPI_GELU || EPI == EPI_DGELU, "epilogue not built for the weight-stationary kernel");
   static_assert(NT == 2 || NT == 3, "column tiles per wave");
   static_assert(NI == KS && LDS_BYTES <= 160 * 1024 && Q_ROUND >= 1, "ring shape");
@@ -116,36 +123,64 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   const int c = lane & 15, g = lane >> 4;
 
   // ------------------------------------------------------------------ A ring: request side
-  int t_issue = t_begin, q_issue = 0;
+  int t_issue = t_begin, q_issue = 0, qa_issue = 0, qa_read = 0;
+  // Lane part of every DMA address, once: (row of the tile, 16-byte chunk) of this lane in DMA instruction k of this wave, as a byte offset from the tile's
+  // first row - the request of a tile is then a scalar base (64-bit, scalar unit) plus a 32-bit lane offset per instruction instead of a 64-bit multiply
+  // chain per instruction and tile (three quarter-rate instructions each, in the auxiliary slot that the partner's matrix slot has to share the issue port
+  // with).  A lane whose row lies beyond the operand's last row takes the tile's first row instead (a select between two offsets, no multiply).
+  // (consecutive lanes read consecutive 16-byte chunks of ONE row: the address unit coalesces a quad of lanes into one 64-byte access.  The first
+  //  form of the image had the rows running fastest - every lane of a quad in another row, i.e. four lookups per quad.)
+  int dma_r[C::NPW];
+  unsigned dma_off[C::NPW], dma_off0[C::NPW];
+#pragma unroll
+  for (int k = 0; k < C::NPW; ++k) {
+    const int inst = wave + k * C::NW;  // (scalar)
+    int r, chunk;
+    if (inst < C::NREG) {
+      r = (inst & 1) * 8 + (lane >> 3);  // row of the tile; the image keeps its 8 chunks of an octet at position kc ^ (r & 6)
+      chunk = (inst >> 1) * 8 + ((lane & 7) ^ (r & 6));
+    } else {
+      r = lane >> 2;                     // last half octet (KS odd): 16 rows x 4 chunks at position kc ^ ((r & 4) >> 1)
+      chunk = (C::KS / 2) * 8 + ((lane & 3) ^ ((r & 4) >> 1));
+    }
+    dma_r[k] = r;
+    dma_off[k] = (unsigned)(r * a.ldp + chunk * 8) * 2u;
+    dma_off0[k] = (unsigned)(chunk * 8) * 2u;
+  }
+  const unsigned aux_off0 = C::AUX_DMA ? (unsigned)(jw0 + (g & 1) * 16 + (g >> 1) * 8) * 2u : 0u;
+  const unsigned aux_off = C::AUX_DMA ? aux_off0 + (unsigned)(c * a.e.ld_aux) * 2u : 0u;
   auto issue = [&]() -> int {  // this wave's share of the DMA of tile t_issue (into ring slot q_issue); returns the number of instructions issued
     int n = 0;
     if (t_issue < t_end) {
       const int row0 = t_issue * 16;
       char* dst = smem + q_issue * C::TILE_BYTES;
+      const char* tbase = reinterpret_cast<const char*>(gP) + (size_t)row0 * a.ldp * 2;
 #pragma unroll
       for (int k = 0; k < C::NPW; ++k) {
         const int inst = wave + k * C::NW;  // (scalar)
         if (inst < C::NI) {
-          int row, chunk;
-          // (consecutive lanes read consecutive 16-byte chunks of ONE row: the address unit coalesces a quad of lanes into one 64-byte access.  The first
-          //  form of the image had the rows running fastest - every lane of a quad in another row, i.e. four lookups per quad.)
-          if (inst < C::NREG) {
-            const int r = (inst & 1) * 8 + (lane >> 3);  // row of the tile; the image keeps its 8 chunks of an octet at position kc ^ (r & 6)
-            row = row0 + r;
-            chunk = (inst >> 1) * 8 + ((lane & 7) ^ (r & 6));
-          } else {
-            const int r = lane >> 2;                     // last half octet (KS odd): 16 rows x 4 chunks at position kc ^ ((r & 4) >> 1)
-            row = row0 + r;
-            chunk = (C::KS / 2) * 8 + ((lane & 3) ^ ((r & 4) >> 1));
-          }
-          row = min(row, a.I - 1);  // rows beyond the operand: a valid row (their products only reach rows the buffer stores drop)
-          dma16(gP + (size_t)row * a.ldp + chunk * 8, dst + inst * 1024);
+          // rows beyond the operand: a valid row (their products only reach rows the buffer stores drop)
+          dma16(tbase + (row0 + dma_r[k] < a.I ? dma_off[k] : dma_off0[k]), dst + inst * 1024);
           ++n;
+        }
+      }
+      if constexpr (C::AUX_DMA) {
+        if (active) {  // the wave's own 16 x WJ piece of the saved derivative: lane (c, g) fetches the 8 columns it will hold after the tile exchange
+          const char* abase = reinterpret_cast<const char*>(a.e.aux) + (size_t)row0 * a.e.ld_aux * 2;
+          const char* ap = abase + (row0 + c < a.I ? aux_off : aux_off0);
+          char* adst = smem + C::AUX_OFF + (qa_issue * C::NW + wave) * C::AUX_WAVE;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ap, (__attribute__((address_space(3))) void*)adst, 16, 0, V4H_SAVED_AUX);
+          ++n;
+          if constexpr (C::NT == 3) {  // third column tile: the lanes with even g hold its halves (the others fetch a valid address and never read it)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap + (32 - (g & 1) * 16) * 2), (__attribute__((address_space(3))) void*)(adst + 1024), 16, 0, V4H_SAVED_AUX);
+            ++n;
+          }
         }
       }
     }
     ++t_issue;
     q_issue = q_issue == C::R - 1 ? 0 : q_issue + 1;
+    qa_issue = qa_issue == C::AUX_SLOTS - 1 ? 0 : qa_issue + 1;
     return sgpr(n);
   };
 
@@ -248,16 +283,18 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   // Pair (column tiles 0, 1): v_permlane16_swap gives every lane 8 consecutive columns - even g: tile 0, odd g: tile 1 -, one 16-byte access per lane.
   // Tile 2 (NT = 3): the same swap against itself, the lanes with even g hold its 8-column halves, the others point outside the buffer.
   constexpr unsigned OOB = 0x7FFFFFF0u;
-  u32x4 aux01, aux2;  // EPI_DGELU: the saved gelu' of the tile, requested in front of the DMA share (its wait must not include that share)
-  auto epi_pre = [&](int t) -> int {
-    if constexpr (C::EPI == EPI_DGELU) {
+  // (Round 5, first form of EPI_DGELU: the saved derivative by buffer loads in front of the DMA share.  The compiler's wait for them was vmcnt(0) - the share
+  //  is requested under a condition, so the only count that is right on every path is zero - and drained the whole ring every interval: 3750-3980 clocks
+  //  per interval against 2540 of the plain store.  Now the derivative arrives through the ring: Gemm3Cfg::AUX_DMA.)
+  //  The strip is read at the head of the auxiliary slot and waited for behind the DMA requests: its LDS latency is not on the slot's critical path.
+  u32x4 aux01, aux2;
+  auto epi_pre = [&](int) -> int {
+    if constexpr (C::AUX_DMA) {
       if (!active) return 0;
-      const int row = t * 16 + c;
-      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.e.aux), 0, (int)min((long)a.I * a.e.ld_aux * 2, 0x7FFFFFF0L), 0x00020000);
-      aux01 = __builtin_amdgcn_raw_buffer_load_b128(rx, (unsigned)(row * a.e.ld_aux + jw0 + (g & 1) * 16 + (g >> 1) * 8) * 2u, 0, V4H_SAVED_AUX);
-      if constexpr (C::NT == 3)
-        aux2 = __builtin_amdgcn_raw_buffer_load_b128(rx, (g & 1) ? OOB : (unsigned)(row * a.e.ld_aux + jw0 + 32 + (g >> 1) * 8) * 2u, 0, V4H_SAVED_AUX);
-      return C::EPI_ST;
+      const unsigned aaddr = lds0 + C::AUX_OFF + (qa_read * C::NW + wave) * C::AUX_WAVE + lane * 16;
+      qa_read = qa_read == C::AUX_SLOTS - 1 ? 0 : qa_read + 1;
+      if constexpr (C::NT == 3) asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(aux01), "=&v"(aux2) : "v"(aaddr));
+      else asm volatile("ds_read_b128 %0, %1" : "=&v"(aux01) : "v"(aaddr));
     }
     return 0;
   };
@@ -276,8 +313,17 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       const __amdgpu_buffer_rsrc_t ro2 = __builtin_amdgcn_make_buffer_rsrc(a.e.out2, 0, (int)min((long)a.I * a.e.ldo2 * 2, 0x7FFFFFF0L), 0x00020000);
       const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, train ? (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L) : 0, 0x00020000);
       f32x4 y[C::NT], d[C::NT];
+      {  // column tiles 0 and 1 on the packed form (v4h_common.h)
+        f32x8 yv, dv;
 #pragma unroll
-      for (int ct = 0; ct < C::NT; ++ct)
+        for (int r = 0; r < 4; ++r) { yv.v[r] = acc[0][r]; yv.v[4 + r] = acc[1][r]; dv.v[r] = 0.f; dv.v[4 + r] = 0.f; }
+        if (train) gelu8_and_grad<bf16>(yv, dv);
+        else gelu8_only<bf16>(yv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { y[0][r] = yv.v[r]; y[1][r] = yv.v[4 + r]; d[0][r] = dv.v[r]; d[1][r] = dv.v[4 + r]; }
+      }
+#pragma unroll
+      for (int ct = 2; ct < C::NT; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (train) {
@@ -299,6 +345,8 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       return C::EPI_OPS;
     } else {  // EPI_DGELU: out = acc * aux
       const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.e.out, 0, (int)min((long)a.I * a.e.ldo * 2, 0x7FFFFFF0L), 0x00020000);
+      if constexpr (C::NT == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aux01), "+v"(aux2));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aux01));
       {
         f32x8 v = swap_pair(acc[0], acc[1]);
         const bf16x8 x = __builtin_bit_cast(bf16x8, aux01);
@@ -326,7 +374,7 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   // Counted wait.  In the steady state the count is one of two constants - (R - 1) epilogues + (R - 2) DMA shares of 1 or 2 instructions - and takes an
   // immediate; anything else (head and tail of the walk, waves without columns) goes through the computed jump (176 clocks per call, measured).
   auto wait_counted = [&](int n) {
-    constexpr int S2 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * 2, S1 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * 1;
+    constexpr int S2 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * (2 + C::AUX_N), S1 = (C::R - 1) * C::EPI_OPS + (C::R - 2) * (1 + C::AUX_N);
     static_assert(S2 <= 63, "vmcnt immediate");
     if (n == S2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S2) : "memory");
     else if (n == S1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S1) : "memory");
