@@ -398,10 +398,16 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
       mk[C::R - 2] = ops;
       ops += epi_post(t);
     } else {
+      // The SIMD's issue arbiter serves its older wave first - the half-0 wave - and a half-1 wave in its auxiliary slot (dependent vector instructions,
+      // first beside the partner's MFMAs, then beside the partner's own auxiliary slot) fell behind: 2170 clocks for the GELU form's slot against 890 for the
+      // same work in half 0, and half 0 then waited 1300 clocks at the barrier.  Raised priority for exactly this slot: 1570 / 600, interval 3400 -> 2920
+      // (sampler +1.9 %, update step +0.3 %; the same priority for both halves' auxiliary slots, or for half 1 throughout: neutral / -0.4 %).
+      __builtin_amdgcn_s_setprio(1);
       if (t > t_begin) ops += epi_pre(t - 1);
       ops += issue();
       mk[C::R - 2] = ops;
       if (t > t_begin) ops += epi_post(t - 1);
+      __builtin_amdgcn_s_setprio(0);
       V4H_G3_STAMP();
       if (active) matrix(slot);
     }
