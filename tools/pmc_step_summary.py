@@ -91,6 +91,8 @@ ALGO = {  # short kernel name -> (read MB per call, written MB per call, what)
     "ln_modulate_bwd8v2_kernel": ((BT * D * 8) / 1e6, (BT * D * 4) / 1e6, "du bf16 + x bf16 + dx bf16 + y bf16 -> dx bf16 + dy bf16"),
     "v4h_gemm3_kernel<Gemm3Cfg<false, 0, 3": ((BT * D * 2 + 3 * D * D * 2) / 1e6, (BT * 3 * D * 2) / 1e6, "qkv forward, weight-stationary: u1 + W -> qkv"),
     "v4h_gemm3_kernel<Gemm3Cfg<false, 0, 2": ((BT * D * 2 + D * D * 2) / 1e6, (BT * D * 2) / 1e6, "attn.proj forward, weight-stationary: o + W -> y1"),
+    "v4h_gemm3_kernel<Gemm3Cfg<false, 6, 2": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "fc1 + GELU forward, weight-stationary: u2 + W -> h + gelu'"),
+    "v4h_gemm3_kernel<Gemm3Cfg<true, 7, 2": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "fc2 dgrad x gelu', weight-stationary: dy + W + gelu' -> dh"),
     "adamw_sched_kernel": (26042528 * 16 / 1e6, 26042528 * 12 / 1e6, "p, g, m, v -> p, m, v"),
     "gemm<bf16,fwd,128x128x64,GELU>": ((BT * D * 2 + M * D * 2) / 1e6, (2 * BT * M * 2) / 1e6, "u2 + W -> h + gelu' (128 x 128 tiles)"),
     "gemm<bf16,dgrad,128x128x64,DGELU>": ((BT * D * 2 + M * D * 2 + BT * M * 2) / 1e6, (BT * M * 2) / 1e6, "dy + W + gelu' -> dh (128 x 128 tiles)"),
