@@ -188,6 +188,34 @@ def test_weight_stationary_gelu_and_dgelu(I):
     _with_kernel(_lib.KERNEL_WS, run)
 
 
+@pytest.mark.parametrize("I", [2048, 2075, 17280])
+@pytest.mark.parametrize("J", [480, 1920])
+def test_weight_stationary_dgelu_exact_with_the_saved_derivative_through_the_ring(I, J):
+    """Out = (P W) * aux on the weight-stationary kernel, where the saved derivative `aux` travels through the kernel's DMA ring into wave-private LDS strips
+    (csrc/v4h_gemm3.h, Gemm3Cfg::AUX_DMA): small-integer operands and power-of-two multipliers make every product and sum exact, so each element must equal
+    the f64 result after the output's bf16 rounding - which pins the (row, column) of every multiplier, for ragged last tiles (rows beyond I take the tile's
+    first row and are dropped) and for a last column slice with idle waves."""
+    lib = _lib.load()
+    K = 480
+    gen = torch.Generator(device=U.DEV).manual_seed(I * 3 + J)
+    s = _lib.stream_ptr(U.DEV)
+    P = _ints((I, K), gen, -2, 3)
+    Wt = _ints((K, J), gen, -2, 3)
+    aux = torch.tensor([0.25, 0.5, 1.0, 2.0, -1.0, -0.5, 0.0, 4.0], device=U.DEV)[torch.randint(0, 8, (I, J), generator=gen, device=U.DEV)].to(torch.bfloat16)
+    ref = ((P.double() @ Wt.double()) * aux.double()).to(torch.bfloat16)
+    out = torch.full((I + 24, J), 7.0, device=U.DEV, dtype=torch.bfloat16)
+
+    def run():
+        _lib.check(lib.v4h_op_gemm_dgelu(_lib.MODES["bf16"], _lib.ptr(P), K, _lib.ptr(Wt), J, _lib.ptr(aux), J, _lib.ptr(out), J, I, J, K, s), "gemm_dgelu")
+
+    _with_kernel(_lib.KERNEL_WS, run)
+    assert torch.equal(out[:I], ref), (I, J, int((out[:I] != ref).sum()))
+    assert bool((out[I:] == 7.0).all())
+    out.fill_(7.0)
+    run()  # the automatic choice: the same kernel for this shape (default classes), or another one with the same exact result
+    assert torch.equal(out[:I], ref) and bool((out[I:] == 7.0).all())
+
+
 # ---------------------------------------------------------------------------------------------------------------- EMA in the fused update, pipelined norm
 def _small_trainer(**kw):
     from vit4hep_amd.trainer import CFMTrainer
