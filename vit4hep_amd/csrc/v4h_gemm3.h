@@ -98,10 +98,7 @@ __device__ unsigned v4h_gemm3_stamp_buf[256 * 8 * G3_ST_N];
 
 // ncs column slices x nrg row groups; wpx = shares per XCD; rcp_ncs = ceil(2^32 / ncs) (share / ncs without a division sequence); row group rg walks
 // tiles [rg * tq + min(rg, tr), ...) with tq = tiles / nrg, tr = tiles % nrg: ranges that differ by at most one tile.
-// Narrow last column slice (at most half of the waves have columns - only half 0 runs, without a ping-pong partner, and its interval is the shorter one): its
-// workgroups come BEHIND the `nfull` shares of the full slices and cut the rows into their own, fewer and longer, row groups (nrg2, tq2, tr2); nrg2 = 0: one grid.
-struct G3Last { int nfull, nrg2, tq2, tr2; };
-template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kernel(const GemmArgs a, int ncs, int nrg, int wpx, unsigned rcp_ncs, int tq, int tr, G3Last last) {
+template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kernel(const GemmArgs a, int ncs, int nrg, int wpx, unsigned rcp_ncs, int tq, int tr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,20 +115,9 @@ template <class C> __global__ __launch_bounds__(C::NTHR, 2) void v4h_gemm3_kerne
   // workgroup -> (column slice, row group).  Blocks are dealt round-robin over the 8 XCDs: block b runs share (b % 8) * wpx + b / 8 of the row-group-major
   // list, so the workgroups of one XCD are consecutive row groups with ALL their column slices - an activation tile is fetched into that L2 once (speed only).
   const int share = (int)(blockIdx.x & 7) * wpx + (int)(blockIdx.x >> 3);
-  int rg, cs, t_begin, t_end;
-  if (last.nrg2 > 0 && share >= last.nfull) {  // (ncs counts the full slices only in this form; rcp_ncs belongs to that count)
-    rg = share - last.nfull;
-    cs = ncs;
-    if (rg >= last.nrg2) return;
-    t_begin = rg * last.tq2 + min(rg, last.tr2);
-    t_end = t_begin + last.tq2 + (rg < last.tr2 ? 1 : 0);
-  } else {
-    if (share >= ncs * nrg) return;
-    rg = sgpr((int)__umulhi((unsigned)share, rcp_ncs));
-    cs = share - rg * ncs;
-    t_begin = rg * tq + min(rg, tr);
-    t_end = t_begin + tq + (rg < tr ? 1 : 0);
-  }
+  if (share >= ncs * nrg) return;
+  const int rg = sgpr((int)__umulhi((unsigned)share, rcp_ncs)), cs = share - rg * ncs;
+  const int t_begin = rg * tq + min(rg, tr), t_end = t_begin + tq + (rg < tr ? 1 : 0);
   const int jw0 = cs * C::BJ + wave * C::WJ;  // this wave's first column
   const bool active = jw0 < a.J;              // (wave-uniform; J is a whole number of wave slices)
   const int c = lane & 15, g = lane >> 4;
@@ -469,29 +455,11 @@ template <class C> int v4h_gemm3_launch(const GemmArgs& a, hipStream_t stream, c
   V4H_CHECK_ARG(((uintptr_t)a.e.out % 16) == 0 && a.e.ldo % 8 == 0 && (long)a.I * a.e.ldo * 2 < 0x7FFFFFF0L, "%s: output must be 16-byte aligned, row stride of whole chunks, below 2 GB", name);
   if (C::EPI == EPI_GELU) V4H_CHECK_ARG(a.e.out2 != nullptr && ((uintptr_t)a.e.out2 % 16) == 0 && a.e.ldo2 % 8 == 0 && (long)a.I * a.e.ldo2 * 2 < 0x7FFFFFF0L, "%s: second output", name);
   if (C::EPI == EPI_DGELU) V4H_CHECK_ARG(a.e.aux != nullptr && ((uintptr_t)a.e.aux % 16) == 0 && a.e.ld_aux % 8 == 0 && (long)a.I * a.e.ld_aux * 2 < 0x7FFFFFF0L, "%s: auxiliary operand", name);
-  int ncs = (a.J + C::BJ - 1) / C::BJ;
-  const int nrt = (a.I + 15) / 16, cus = v4h_compute_units();
-  int nrg = cus / ncs;
+  const int ncs = (a.J + C::BJ - 1) / C::BJ, nrt = (a.I + 15) / 16;
+  int nrg = v4h_compute_units() / ncs;
   if (nrg > nrt) nrg = nrt;
-  V4H_CHECK_ARG(nrg >= 1, "%s: %d column slices do not fit the %d compute units", name, ncs, cus);
-  // a last slice with columns for at most half of the waves (J = 1920 with two column tiles per wave: 7.5 slices) gets fewer, longer row groups of its own:
-  // 7 x 33 + 25 workgroups instead of 8 x 32 (32.7 instead of 33.75 tiles for the full slices' workgroups, 43.2 for the narrow one's, whose interval without a
-  // partner is about 0.75 of the full one).  Measured: 264.3 / 264.5 vs 263.1 / 264.4 steps/s, sampler 1555 / 1569 vs 1549 / 1552 showers/s; 7 x 34 + 18: 257.4 / 258.7.
-  G3Last last{0, 0, 0, 0};
-  const int last_waves = ((a.J - (ncs - 1) * C::BJ) + C::WJ - 1) / C::WJ;
-  static const int tune = [] { const char* e = getenv("V4H_GEMM3_LAST"); return e ? atoi(e) : -1; }();  // tuning hook: row groups of the narrow slice (0 = one grid)
-  if (ncs >= 2 && 2 * last_waves <= C::NW && tune != 0 && nrt >= cus) {
-    const int nf = ncs - 1;
-    int g2 = tune > 0 ? tune : (int)(cus * 0.62 / (nf + 0.62) + 0.5);
-    int g1 = (cus - g2) / nf;
-    g2 = cus - g1 * nf;
-    if (g1 >= 1 && g2 >= 1 && g2 <= nrt) {
-      last = G3Last{nf * g1, g2, nrt / g2, nrt % g2};
-      ncs = nf;
-      nrg = g1;
-    }
-  }
-  const int wpx = ((last.nrg2 > 0 ? last.nfull + last.nrg2 : ncs * nrg) + 7) / 8;
+  V4H_CHECK_ARG(nrg >= 1, "%s: %d column slices do not fit the %d compute units", name, ncs, v4h_compute_units());
+  const int wpx = (ncs * nrg + 7) / 8;
   const unsigned rcp_ncs = (unsigned)((0x100000000ULL + ncs - 1) / ncs);  // exact quotient for share < 2^16
   const int tq = nrt / nrg, tr = nrt % nrg;
   static DeviceOnce lds_attr;
@@ -499,9 +467,9 @@ template <class C> int v4h_gemm3_launch(const GemmArgs& a, hipStream_t stream, c
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 4096);
       }, name, "reserve the ring's LDS")) return rc;
 #ifdef V4H_GEMM3_STAMPS
-  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES + 4096, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr, last);
+  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES + 4096, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
 #else
-  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr, last);
+  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
 #endif
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;
