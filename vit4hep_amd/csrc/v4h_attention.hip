@@ -837,7 +837,7 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
       int rc = set_lds(attn_bwd_fused_kernel<T, 80, NW>, lds, "attn_bwd_fused");
       if (rc) return rc;
       const int nitems = B * H;
-      hipLaunchKernelGGL((attn_bwd_fused_kernel<T, 80, NW>), dim3(v4h_compute_units()), dim3(64 * NW), lds, s, (const T*)qkv, (const T*)o, (const T*)dout, lse,
+      V4H_LAUNCH((attn_bwd_fused_kernel<T, 80, NW>), dim3(v4h_compute_units()), dim3(64 * NW), lds, s, (const T*)qkv, (const T*)o, (const T*)dout, lse,
                          (T*)dqkv, Tn, H, nitems, 1.0f / sqrtf((float)DH));
       V4H_CHECK_LAUNCH("attn_bwd_fused");
       return V4H_OK;
@@ -856,7 +856,7 @@ template <typename T> int attn_bwd_t(const void* qkv, const void* o, const void*
       const size_t lds2 = img2 + AL_PAD + 2 * AL_NT * 16 * sizeof(float);
       rc = set_lds(attn_bwd_dkv_img_kernel<AL_NT, AL_NW, 2, 1>, lds2, "attn_bwd_long_dkv");
       if (rc) return rc;
-      hipLaunchKernelGGL((attn_bwd_dkv_img_kernel<AL_NT, AL_NW, 2, 1>), dim3(v4h_compute_units()), dim3(64 * AL_NW), lds2, s, (const bf16*)qkv, (const bf16*)dout, lse,
+      V4H_LAUNCH((attn_bwd_dkv_img_kernel<AL_NT, AL_NW, 2, 1>), dim3(v4h_compute_units()), dim3(64 * AL_NW), lds2, s, (const bf16*)qkv, (const bf16*)dout, lse,
                          (const float*)delta, (bf16*)dqkv, Tn, H, B * H, scale);
       V4H_CHECK_LAUNCH("attn_bwd_long_dkv");
       return V4H_OK;

@@ -14,6 +14,7 @@
 //   acc[r] = Out[lane_side_idx = lane & 15][regs_side_idx = 4 * (lane >> 4) + r]
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -235,6 +236,22 @@ V4H_DEV void wait_vmcnt64(int n) {
 #define V4H_ERR_UNSUPPORTED 3
 
 void v4h_set_error(const char* fmt, ...);
+// Completion signal of ONE launch as an event (round 5).  The backward pass hands a kernel's output to the weight-gradient stream the moment the kernel ends; an
+// event RECORDED behind the launch is a marker packet of its own in the main queue (1.1-1.4 us per record, ~30 per update step:
+// tools/experiments/ext_launch_event.hip), the stop event of hipExtLaunchKernelGGL is the dispatch packet's own completion signal and costs nothing.  The runtime
+// arms the event (v4h_tls_stop_event), the LAST launch of the producing operator takes it (V4H_LAUNCH; the other launch sites never look), and the runtime falls
+// back to a record if nobody did (v4h_runtime.hip: arm_fork / complete_fork).
+extern thread_local hipEvent_t v4h_tls_stop_event;
+#define V4H_LAUNCH(kernel, grid, block, lds, stream, ...)                                        \
+  do {                                                                                           \
+    if (v4h_tls_stop_event != nullptr) {                                                         \
+      hipEvent_t stop_ = v4h_tls_stop_event;                                                     \
+      v4h_tls_stop_event = nullptr;                                                              \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop_, 0, __VA_ARGS__);   \
+    } else {                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                         \
+    }                                                                                            \
+  } while (0)
 #define V4H_CHECK_ARG(cond, ...)                 \
   do {                                           \
     if (!(cond)) {                               \

@@ -1150,8 +1150,8 @@ int ln_resid_modulate_fwd(Mode m, const void* x, const void* y, const float* gat
 int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
   V4H_CHECK_ARG(a.D % 4 == 0 && a.D <= 1024, "ln_modulate_bwd: hidden_dim %d unsupported", a.D);
   // 16 rows per workgroup, 2 rows in flight per wave: measured best (4 rows in flight or 32-48 rows per workgroup: -1...-6 % end to end)
-#define V4H_LNB_LAUNCH(TT, MAXV) hipLaunchKernelGGL((ln_modulate_bwd_kernel<TT, MAXV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
-#define V4H_LNB8_LAUNCH(TT, NV) hipLaunchKernelGGL((ln_modulate_bwd8_kernel<TT, NV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
+#define V4H_LNB_LAUNCH(TT, MAXV) V4H_LAUNCH((ln_modulate_bwd_kernel<TT, MAXV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
+#define V4H_LNB8_LAUNCH(TT, NV) V4H_LAUNCH((ln_modulate_bwd8_kernel<TT, NV, 16, 2>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
   auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
   const bool al = al16(a.du) && al16(a.x) && al16(a.dx_in) && al16(a.dx_out) && al16(a.dx_out_t) && al16(a.y) && al16(a.dy) && al16(a.scale) && al16(a.gate) &&
                   a.ld_mod % 4 == 0 && a.ld_mod_gate % 4 == 0;
@@ -1170,7 +1170,7 @@ int ln_modulate_bwd(Mode m, const LnBwdArgs& a, hipStream_t s) {
     // 16 rows per workgroup of 4 waves, one row per wave at a time.  (Round 4: 8 rows.  With the bf16 streams of round 5 the per-sample float atomics of a
     // workgroup - 3 x 480 floats whatever its row count, 12.4 MB per launch at 8 rows against 100 MB of streams - weigh more: 16 rows halve them, 68 MB less
     // per step, 256.5 vs 256.0 steps/s; 24 rows 255.3.)
-#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) hipLaunchKernelGGL((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 16, 4, 1, A, B_, C_, D_>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
+#define V4H_LNB2(TT, XT, GT, A, B_, C_, D_) V4H_LAUNCH((ln_modulate_bwd8v2_kernel<TT, XT, GT, 1, 16, 4, 1, A, B_, C_, D_>), dim3((a.T + 15) / 16, a.B), dim3(256), 0, s, a)
 #define V4H_LNB2_COMBO(TT, XT, GT)                                     \
   do {                                                                 \
     if (combo == 0) V4H_LNB2(TT, XT, GT, false, true, true, false);    \

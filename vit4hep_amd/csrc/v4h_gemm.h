@@ -1000,7 +1000,7 @@ template <class C> int v4h_gemm_launch(GemmArgs a, int splitk, hipStream_t strea
           return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
         }, name, "reserve the LDS of the tile")) return rc;
   }
-  hipLaunchKernelGGL(v4h_gemm_kernel<C>, grid, dim3(C::NT), C::LDS_BYTES, stream, a);
+  V4H_LAUNCH(v4h_gemm_kernel<C>, grid, dim3(C::NT), C::LDS_BYTES, stream, a);
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;
 }

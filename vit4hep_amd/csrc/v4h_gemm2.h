@@ -570,9 +570,9 @@ template <class C> int v4h_gemm2_launch(GemmArgs a, int splitk, hipStream_t stre
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm2_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 2048);
       }, name, "reserve the ring's LDS")) return rc;
 #ifdef V4H_GEMM2_STAMPS
-  hipLaunchKernelGGL(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES + 2048, stream, a);
+  V4H_LAUNCH(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES + 2048, stream, a);
 #else
-  hipLaunchKernelGGL(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES, stream, a);
+  V4H_LAUNCH(v4h_gemm2_kernel<C>, dim3((unsigned)nblocks), dim3(C::NT), C::LDS_BYTES, stream, a);
 #endif
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;

@@ -467,9 +467,9 @@ template <class C> int v4h_gemm3_launch(const GemmArgs& a, hipStream_t stream, c
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&v4h_gemm3_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES + 4096);
       }, name, "reserve the ring's LDS")) return rc;
 #ifdef V4H_GEMM3_STAMPS
-  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES + 4096, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
+  V4H_LAUNCH(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES + 4096, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
 #else
-  hipLaunchKernelGGL(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
+  V4H_LAUNCH(v4h_gemm3_kernel<C>, dim3((unsigned)(8 * wpx)), dim3(C::NTHR), C::LDS_BYTES, stream, a, ncs, nrg, wpx, rcp_ncs, tq, tr);
 #endif
   V4H_CHECK_LAUNCH(name);
   return V4H_OK;

@@ -112,6 +112,27 @@ static int side_wait_main(const v4h_plan& p, hipStream_t main) {
   if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(p.side, e, 0) != hipSuccess) { v4h_set_error("fork failed"); return V4H_ERR_HIP; }
   return V4H_OK;
 }
+// The side stream waits for the operator the caller enqueues on the main stream between arm_fork() and complete_fork() - and for nothing behind it: the
+// operator's last launch carries the event as its completion signal (V4H_LAUNCH); an operator that did not take it gets the record of side_wait_main().
+thread_local hipEvent_t v4h_tls_stop_event = nullptr;
+static const bool g_stop_events = !(getenv("V4H_STOP_EVENTS") && getenv("V4H_STOP_EVENTS")[0] == '0');  // A/B hook
+struct ForkArm { hipEvent_t e; bool armed; };
+static ForkArm arm_fork(const v4h_plan& p, hipStream_t main) {
+  ForkArm f{p.ev[p.evi++ & 7], false};
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(main, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;  // (a captured launch has no completion signal to hand out)
+  f.armed = g_stop_events && !capturing;
+  v4h_tls_stop_event = f.armed ? f.e : nullptr;
+  return f;
+}
+static int complete_fork(const v4h_plan& p, const ForkArm& f, hipStream_t main, bool call_ok) {
+  const bool taken = f.armed && v4h_tls_stop_event == nullptr;
+  v4h_tls_stop_event = nullptr;
+  if (!call_ok) return V4H_OK;  // (the operator failed: its error stands)
+  if (!taken && hipEventRecord(f.e, main) != hipSuccess) { v4h_set_error("fork failed"); return V4H_ERR_HIP; }
+  if (hipStreamWaitEvent(p.side, f.e, 0) != hipSuccess) { v4h_set_error("fork failed"); return V4H_ERR_HIP; }
+  return V4H_OK;
+}
 // `waiter` waits for everything enqueued on `signaler` so far
 static int stream_wait(const v4h_plan& p, hipStream_t waiter, hipStream_t signaler) {
   if (waiter == signaler) return V4H_OK;
@@ -849,6 +870,15 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
   if (stage_first == 0) p->mark_live = 0;
   // residual-stream gradient ping-pong: after stage s the live buffer is dx[(s+1)&1]... tracked explicitly below
   auto dxbuf = [&](int k) { return (k & 1) ? w.dxB : w.dxA; };
+  // `forked(op)`: run the operator on the main stream and make the weight-gradient stream wait for exactly it (its completion signal, see arm_fork)
+  auto forked = [&](auto&& op) -> int {
+    if (!g_overlap_wgrad) return op();
+    const ForkArm f = arm_fork(*p, c.s);
+    const int rc = op();
+    const int rc2 = complete_fork(*p, f, c.s, rc == V4H_OK);
+    return rc != V4H_OK ? rc : rc2;
+  };
+  bool pre_forked = false;  // the side stream already waits for the kernel that wrote the next block's dy (the LayerNorm backward that ended the previous stage)
   // A backward pass issued as ONE call handles every adaLN Linear of the step together at the end (one cast, one grouped weight-gradient
   // contraction, one contraction for d silu(cond)) instead of three latency-bound launches per block: the d-modulation buffer is then one
   // (B, ldmod) table like the forward's.  Staged passes (gradient buckets reduced while later stages run) need each block's adaLN
@@ -916,7 +946,8 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       l.dx_out = dxbuf(0); l.dshift = dmodf; l.dscale = dmodf + D; l.ld_dmod = lddf;
       l.y = w.blk[depth - 1].y2; l.gate = w.mod[depth - 1] + 5 * D; l.ld_mod_gate = p->ldmod(); l.dy = w.dy[(depth - 1) & 1]; l.dgate = dmod(depth - 1) + 5 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
-      RUN(ln_modulate_bwd(m, l, c.s));
+      RUN(forked([&] { return ln_modulate_bwd(m, l, c.s); }));
+      pre_forked = g_overlap_wgrad;
       if (!batch_ada) RUN(adaln_backward(c, dmodf, 2 * D, p->fin(F_ADAW), p->fin(F_ADAB), grads));
       RUN(stage_done(0, ov0 ? p->side : c.s));  // final-layer gradients: all on the weight-gradient stream
     } else if (st <= depth) {
@@ -948,12 +979,14 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       };
       if (ov) RUN(main_wait_mark(*p, S_BLK0 + (i & 1), c.s));
       // --- MLP branch (timm Mlp, nn/vit.py:317-322,332) ---
-      RUN(fork_wgrad(0));  // dy (and h) ready
+      if (pre_forked) RUN(wg(0));  // dy (and h) ready: the side stream waits for the kernel that wrote dy since the end of the previous stage
+      else RUN(fork_wgrad(0));
+      pre_forked = false;
       if (ov) RUN(side_mark(*p, S_FC2));
       GemmArgs a = gargs(dy_i, D, c.W(p->blk(i, B_FC2W)), M, BT, M, D);
       a.e.out = dh_i; a.e.ldo = M; a.e.aux = b.hgrad; a.e.ld_aux = M;
-      RUN(gemm_dgrad(m, EPI_DGELU, a, c.s));
-      RUN(fork_wgrad(1));  // dhpre ready
+      RUN(forked([&] { return gemm_dgrad(m, EPI_DGELU, a, c.s); }));
+      RUN(wg(1));  // dhpre ready
       a = gargs(dh_i, M, c.W(p->blk(i, B_FC1W)), D, BT, D, M);
       a.e.out = w.du; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
@@ -963,14 +996,14 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
       l.dx_in = dx_in; l.dx_out = dx_mid; l.dshift = dmod(i) + 3 * D; l.dscale = dmod(i) + 4 * D; l.ld_dmod = ldd;
       l.y = b.y1; l.gate = w.mod[i] + 2 * D; l.ld_mod_gate = p->ldmod(); l.dy = dy2_i; l.dgate = dmod(i) + 2 * D; l.ld_dgate = ldd;
       l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
-      RUN(ln_modulate_bwd(m, l, c.s));
+      RUN(forked([&] { return ln_modulate_bwd(m, l, c.s); }));
       // --- attention branch (nn/vit.py:425-454,331) ---
-      RUN(fork_wgrad(2));  // dy2 ready
+      RUN(wg(2));  // dy2 ready
       a = gargs(dy2_i, D, c.W(p->blk(i, B_PROJW)), D, BT, D, D);
       a.e.out = w.dof; a.e.ldo = D;
       RUN(gemm_dgrad(m, EPI_STORE, a, c.s));
-      RUN(attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, dq_i, B, T, p->H, p->DH, c.s));
-      RUN(fork_wgrad(3));  // dqkv ready
+      RUN(forked([&] { return attention_bwd(m, b.qkv, b.o, w.dof, b.lse, w.delta, dq_i, B, T, p->H, p->DH, c.s); }));
+      RUN(wg(3));  // dqkv ready
       if (ov) RUN(side_mark(*p, S_BLK0 + (i & 1)));
       a = gargs(dq_i, 3 * D, c.W(p->blk(i, B_QKVW)), D, BT, D, 3 * D);
       a.e.out = w.du; a.e.ldo = D;
@@ -988,7 +1021,12 @@ static int backward_impl(const v4h_plan* p, int32_t B, const void* const* params
         l.dx_out_t = w.dx0_t;  // bottom of the stack: only the operand-typed copy is needed
       }
       l.B = B; l.T = T; l.D = D; l.x16 = p->x16; l.g16 = p->g16;
-      RUN(ln_modulate_bwd(m, l, c.s));
+      if (i > 0) {  // writes dy of block i - 1: that block's first weight gradient waits for this kernel
+        RUN(forked([&] { return ln_modulate_bwd(m, l, c.s); }));
+        pre_forked = ov;
+      } else {
+        RUN(ln_modulate_bwd(m, l, c.s));
+      }
       if (!batch_ada) RUN(adaln_backward(c, dmod(i), 6 * D, p->blk(i, B_ADAW), p->blk(i, B_ADAB), grads));
       RUN(stage_done(st, ws_));  // the block's weight gradients (and, unbatched, its adaLN gradients) are the last thing in the side queue
     } else {
