@@ -19,7 +19,7 @@ if os.path.exists(f"{R}/ab_in_context.txt"):
         "# In-context A/B of the switches the library keeps (tools/refresh_profiles.sh, part 3): two interleaved rounds on one box, each line one full `bench.py` run\n"
         "# (40 timed steps; sampling at batch 256).  V4H_GEMM2=-1 is the default build.  Round-5 levers switched off one at a time: VIT4HEP_AMD_RESIDUAL=f32 / x_bf16 /\n"
         "# dx_bf16 (storage of the residual stream and of its gradient; default bf16 for both), V4H_GEMM3=0 / 3 / 39 / 63 (no class / qkv + proj forward /\n"
-        "# + both GELU forwards / every K = 480 class on the weight-stationary kernel; default 55 = all but the plain dgrad); then the older ones: gradient buffer zero-filled\n"
+        "# + both GELU forwards / every K = 480 class on the weight-stationary kernel; default 55 = all but the plain dgrad), V4H_STOP_EVENTS=0 (recorded events instead of completion signals for the backward's forks); then the older ones: gradient buffer zero-filled\n"
         "# and accumulated into, 128 x 160 tiles where the GELU / DGELU classes run on the two-workgroup kernel,\n"
         "# round-2 LayerNorm backward, pipelined update, 0 / 8 = two-workgroup / ring kernel everywhere, whole-K kernels off, round-2 attention, 4 K-splits, per-block adaLN,\n"
         "# no weight-gradient stream.\n"

@@ -51,7 +51,7 @@ fi
 if has 3; then
 # in-context A/B of the alternatives that are kept behind switches (interleaved, same box)
 for r in 1 2; do
-  for v in "V4H_GEMM2=-1" "VIT4HEP_AMD_RESIDUAL=f32" "VIT4HEP_AMD_RESIDUAL=x_bf16" "VIT4HEP_AMD_RESIDUAL=dx_bf16" "V4H_GEMM3=0" "V4H_GEMM3=3" "V4H_GEMM3=39" "V4H_GEMM3=63" "V4H_OVERWRITE_GRADS=0" "V4H_MLP_TILE=0" "V4H_LNB_V2=0" "V4H_PIPELINE_UPDATE=1" "V4H_GEMM2=0" "V4H_GEMM2=8" "V4H_GEMM_SMALL=0" "V4H_ATTN_DENSE=0" "V4H_WGRAD_WGS=-4" "V4H_BATCH_ADALN=0" "V4H_WGRAD_OVERLAP=0"; do
+  for v in "V4H_GEMM2=-1" "VIT4HEP_AMD_RESIDUAL=f32" "VIT4HEP_AMD_RESIDUAL=x_bf16" "VIT4HEP_AMD_RESIDUAL=dx_bf16" "V4H_GEMM3=0" "V4H_GEMM3=3" "V4H_GEMM3=39" "V4H_GEMM3=63" "V4H_STOP_EVENTS=0" "V4H_OVERWRITE_GRADS=0" "V4H_MLP_TILE=0" "V4H_LNB_V2=0" "V4H_PIPELINE_UPDATE=1" "V4H_GEMM2=0" "V4H_GEMM2=8" "V4H_GEMM_SMALL=0" "V4H_ATTN_DENSE=0" "V4H_WGRAD_WGS=-4" "V4H_BATCH_ADALN=0" "V4H_WGRAD_OVERLAP=0"; do
     echo -n "$v  " >> $out/ab_in_context.txt
     env $v python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-op-rates --no-other --no-box 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], 'steps/s', r['ms_per_step'], 'ms', r['sampling']['rk4']['showers_per_s'], 'showers/s (RK4)')" >> $out/ab_in_context.txt
   done
