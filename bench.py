@@ -19,10 +19,11 @@ import os
 import sys
 import time
 
-# More hardware queues than HIP's default 4, before the runtime starts: the weight-gradient stream, torch's communication stream
-# and RCCL's own streams must not be multiplexed onto the compute stream's queue (docs/history_r01-r04.md section 6; the library also gives its
-# side stream its own priority class, which is what makes the overlap robust when this variable is not set).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES is left at the runtime's default.  Rounds 3-5 set it to 8 here ("every stream its own hardware queue"); the overlap does not need it - the
+# library's weight-gradient stream and the reducer's communication stream are priority streams with queues of their own, 4 / 8 / 16 measured the same at N = 1
+# (profiles/r04_notes.md) - and with 8 the two-rank rehearsal of the full-size step DEADLOCKED in the reducer's finish() (both ranks on one card, gloo's staging
+# streams on top of the library's: 4 and 24 queues finish, 8 hangs: tools/experiments/rehearsal_bisect.sh, profiles/r05_notes.md section 10).  A value a run beside
+# RCCL's own streams could hang on is not worth a neutral knob.
 
 import torch  # noqa: E402
 
@@ -482,6 +483,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # before anything touches the GPU in this process
 
+    # V4H_BENCH_WATCHDOG=<seconds>: dump every thread's Python stack and exit if the run is still going by then (a hung collective or kernel then leaves a
+    # traceback instead of a silent timeout of the caller)
+    if os.environ.get("V4H_BENCH_WATCHDOG"):
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["V4H_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

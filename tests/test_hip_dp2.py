@@ -98,19 +98,22 @@ def test_two_rank_hip_trainer_matches_single_process_on_the_whole_batch(mode, gr
         assert np.array_equal(out[0][2][k], out[1][2][k]) or U.rel_err(torch.from_numpy(out[0][2][k]), torch.from_numpy(out[1][2][k])) < 1e-6, k
 
 
-def test_bench_gpus_2_launches_its_ranks_rehearsal():
+@pytest.mark.parametrize("workload,global_batch,extra", [("ds2_d2", 16, []), ("ds2", 256, ["--lean", "--no-box"])])
+def test_bench_gpus_2_launches_its_ranks_rehearsal(workload, global_batch, extra):
     """`python bench.py --gpus 2` end to end on the one-GPU box (V4H_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo transport): the parent spawns the ranks through
-    torch.distributed.run before touching the GPU, rank 0's JSON line comes back with n_gpus 2."""
+    torch.distributed.run before touching the GPU, rank 0's JSON line comes back with n_gpus 2.  The full-size case (depth 6, eight gradient buckets per step) is
+    the one that deadlocked in BucketReducer.finish() while bench.py set GPU_MAX_HW_QUEUES=8 (round 5): the watchdog turns a hang into a traceback."""
     import json
     import subprocess
     import sys
 
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GPU_MAX_HW_QUEUES")}
     env["V4H_BENCH_REHEARSAL"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "ds2_d2"], env=env, capture_output=True,
-                       text=True, timeout=900)
+    env["V4H_BENCH_WATCHDOG"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload, *extra], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1])
-    assert rec["n_gpus"] == 2 and rec["rehearsal"] is True and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 16
+    assert rec["n_gpus"] == 2 and rec["rehearsal"] is True and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == global_batch
     assert np.isfinite(rec["loss"]) and rec["value"] > 0
